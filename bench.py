@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the kaamer k-mer search path on MI355X.
+
+Metric (BASELINE.json): k-mer lookups/sec (+ query seqs/sec) and the fraction of
+the HBM-bandwidth roofline.  One "step" = one pass of the hot path (prep ->
+probe/count kernel -> scan -> gather) over one batch of synthetic queries that
+is already resident in HBM.
+
+N = 1 workload: BASELINE.json configs[1] — Swiss-Prot-sized synthetic DB
+(560 000 proteins, ~2e8 residues) resident in one MI355X, 10 000 protein
+queries per batch (seed 20261003).
+N > 1: the DB fits one GPU, so ranks are replicas (no data-path collective):
+every rank holds the table and searches its own batch of 10 000 queries;
+value = all ranks' lookups / max-over-ranks time ("weak").
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+
+
+def _tame_malloc():
+    # first touch of fresh pages is very slow on these VMs: keep freed memory in the heap
+    try:
+        libc = ctypes.CDLL("libc.so.6")
+        libc.mallopt(-3, 2 ** 31 - 1)  # M_MMAP_THRESHOLD
+        libc.mallopt(-1, 2 ** 31 - 1)  # M_TRIM_THRESHOLD
+    except Exception:
+        pass
+
+
+def log(*a):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(oix, queries, seconds=12.0, threads=None):
+    """The CPU restatement of the reference algorithm (oracle/, kind "port"),
+    multi-threaded across queries like the reference's nbOfThreads workers
+    (search_protein.go:58), on a bounded sample of the same batch."""
+    from concurrent.futures import ThreadPoolExecutor
+    nq = len(queries[1]) - 1
+    threads = threads or min(os.cpu_count() or 1, 16)
+    block = 25
+    done = {"q": 0, "lookups": 0}
+    t_start = time.time()
+
+    def work(tid):
+        lookups = 0
+        nqd = 0
+        b = tid * block
+        while b < nq and time.time() - t_start < seconds:
+            e = min(nq, b + block)
+            r = oix.batch(queries, "protein", b, e)   # ctypes releases the GIL
+            lookups += r["n_lookup"]
+            nqd += e - b
+            b += threads * block
+        return lookups, nqd
+
+    with ThreadPoolExecutor(threads) as ex:
+        parts = list(ex.map(work, range(threads)))
+    dt = time.time() - t_start
+    lookups = sum(p[0] for p in parts)
+    nqd = sum(p[1] for p in parts)
+    return {"value": lookups / dt, "unit": "k-mer lookups/s", "cores": threads, "kind": "port",
+            "sample": "%d of %d queries of the batch (%d lookups) in %.1f s; oracle = sorted (key,id) array + "
+                      "binary search, not Badger" % (nqd, nq, lookups, dt),
+            "queries_per_s": nqd / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--db-proteins", type=int, default=560000)
+    ap.add_argument("--queries", type=int, default=10000)
+    ap.add_argument("--lds-slots", type=int, default=0)
+    ap.add_argument("--load-factor", type=float, default=0.5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--check", type=int, default=50, help="queries checked against the oracle after timing")
+    args = ap.parse_args()
+
+    _tame_malloc()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+    torch.cuda.set_device(local_rank)
+
+    from kaamer_amd import api, workload
+
+    t0 = time.time()
+    db = workload.make_db(args.db_proteins)
+    log("DB: %d proteins, %d residues (%.1fs)" % (args.db_proteins, int(db[1][-1]), time.time() - t0))
+    t0 = time.time()
+    img = api.Image.from_proteins(packed=db, load_factor=args.load_factor)
+    st = img.stats()
+    log("image built in %.1fs: %s" % (time.time() - t0, st))
+    t0 = time.time()
+    ix = api.Index.from_image(img, local_rank)
+    img.close()
+    log("index resident in HBM (%.2f GB) in %.1fs" % ((st["n_buckets"] * 64 + st["arena_words"] * 4) / 1e9, time.time() - t0))
+
+    # every rank searches its own batch (replicas): same generator, rank-specific seed
+    q = workload.make_protein_queries(db, args.queries, seed=workload.SEED + 1 + 1000 * rank)
+    qbuf, qoff = q
+    d_buf = torch.from_numpy(qbuf).cuda()
+    d_off = torch.from_numpy(qoff.view(np.int64)).cuda()
+    ws = api.Workspace(ix, len(qbuf), args.queries, lds_slots=args.lds_slots)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        return ws.search_device(d_buf.data_ptr(), d_off.data_ptr(), args.queries, len(qbuf), stream=stream)
+
+    for _ in range(args.warmup):
+        step()
+    counters = ws.finish(stream)  # also validates the batch (capacity / overflow)
+    ws.reset_timers()
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_start
+    counters = ws.finish(stream)
+    search_ms, total_ms, n_calls = ws.kernel_ms_sum()
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    lk = torch.tensor([float(counters["n_lookup"]), float(counters["n_queries"])], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lk, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    lookups_per_step = float(lk[0].item())
+    queries_per_step = float(lk[1].item())
+
+    # ---- roofline of the dominant kernel (kmer_search_kernel), HBM bound -------------------
+    # algorithmic bytes per launch, exact kernel-side counters:
+    #   1 B per query residue + 64 B per bucket inspected + 4 B per arena word that must be
+    #   read (list header + ids) + 12 B per emitted hit (pid, kmatch, first_pos)
+    c = counters
+    alg_bytes = c["n_in"] + 64 * c["n_probe"] + 4 * (c["n_lists"] + c["n_list_ids"]) + 12 * c["n_hits"]
+    kern_s = (search_ms / max(n_calls, 1)) / 1e3
+    achieved = alg_bytes / kern_s / 1e9 if kern_s > 0 else 0.0
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "kernel": "kmer_search_kernel", "kernel_ms": kern_s * 1e3,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "bytes_per_lookup": alg_bytes / max(c["n_lookup"], 1),
+                "min_bytes_8B_slot": c["n_in"] + 8 * c["n_lookup"] + 4 * (c["n_lists"] + c["n_list_ids"]) + 12 * c["n_hits"]}
+
+    out = {
+        "metric": "k-mer lookups/sec", "value": lookups_per_step * args.steps / elapsed,
+        "unit": "k-mer lookups/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": "configs[1]: Swiss-Prot-sized synthetic DB (%d proteins, %d residues, %d distinct "
+                               "7-mers) resident in HBM; %d protein queries per GPU per step"
+                               % (args.db_proteins, int(db[1][-1]), st["n_keys"], args.queries),
+                   "parallelism": "replicas x%d (no collective)" % world if world > 1 else "single GPU",
+                   "seed": workload.SEED},
+        "query_seqs_per_s": queries_per_step * args.steps / elapsed,
+        "counters_per_step_rank0": c,
+        "roofline": roofline,
+    }
+
+    if rank == 0:
+        want_cpu = not args.no_cpu_baseline and world == 1
+        if args.check or want_cpu:
+            from oracle import oracle as O  # the checker / the reported CPU baseline, never the product
+            t0 = time.time()
+            oix = O.Index.from_proteins(None, packed=db)
+            log("oracle index built in %.1fs" % (time.time() - t0))
+            if args.check:
+                sub = workload.unpack(q)[:args.check]
+                res = ix.search(sub)
+                for i, s in enumerate(sub):
+                    exp = {}
+                    if O.size_in_kmer(s) >= 7:
+                        pid, km, _ = oix.search(s)
+                        exp = dict(zip(pid.tolist(), km.tolist()))
+                    assert res.hits(i) == exp, "bench: query %d differs from the oracle" % i
+                out["parity_checked_queries"] = len(sub)
+                log("parity: %d queries of the timed batch bit-exact vs oracle" % len(sub))
+            if want_cpu:
+                out["cpu_baseline"] = cpu_baseline(oix, q, seconds=args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,245 @@
+/*
+ * kaamer_hip.h — C ABI of libkaamer_hip.so, the MI355X (gfx950) k-mer search
+ * path for kaamer.
+ *
+ * This is the drop-in boundary.  The reference (zorino/kaamer) has no FFI; the
+ * seam is the Go function boundary between the search drivers and the hot
+ * path.  Each entry point cites the reference code it replaces (paths under
+ * the reference tree).  A cgo shim binds exactly these symbols — see
+ * INTEGRATION.md.
+ *
+ * Conventions
+ *   - every call returns KAAMER_OK (0) or a negative kaamer_status; nothing
+ *     throws or aborts (the reference log.Fatal()s);
+ *   - kaamer_last_error() returns a thread-local message for the last failure;
+ *   - input pointers are borrowed for the duration of the call only (cgo rule);
+ *   - outputs of the host-buffer calls are library-owned until the matching
+ *     *_free call;
+ *   - plain pointers and sizes only, no C++ or torch types.
+ */
+#ifndef KAAMER_HIP_H
+#define KAAMER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KAAMER_ABI_VERSION 1
+#define KAAMER_KMER_SIZE 7 /* pkg/search/search.go:45, pkg/makedb/makedb.go:30 */
+
+typedef enum {
+    KAAMER_OK = 0,
+    KAAMER_E_ARG = -1,       /* bad argument                                   */
+    KAAMER_E_IO = -2,        /* file open/read/write/format                    */
+    KAAMER_E_NOMEM = -3,     /* host or device allocation failed               */
+    KAAMER_E_HIP = -4,       /* a HIP runtime call failed (no device, ...)     */
+    KAAMER_E_CAPACITY = -5,  /* a workspace bound was exceeded; enlarge, retry */
+    KAAMER_E_FORMAT = -6     /* index image/version mismatch                   */
+} kaamer_status;
+
+/* search.go:41-44 */
+enum { KAAMER_NUCLEOTIDE = 0, KAAMER_PROTEIN = 1, KAAMER_READS = 2 };
+
+const char *kaamer_last_error(void);
+int kaamer_abi_version(void);
+
+/* ------------------------------------------------------------------------- */
+/* K-mer codec (host) — replaces K_.EncodeKmer / CreateBytesKey,              */
+/* pkg/kvstore/k_store.go:66-76,91-117.                                       */
+/* ------------------------------------------------------------------------- */
+uint32_t kaamer_encode_kmer(const uint8_t kmer[KAAMER_KMER_SIZE]);
+
+/* ------------------------------------------------------------------------- */
+/* Builder — the GPU-layout emitter beside pkg/makedb + pkg/indexdb.           */
+/*   pairs  = what makedb's emit loops write into kmer_store                   */
+/*            (inputFASTA.go:245-248, inputTSV.go:236-239, inputEMBL.go:309-312,*/
+/*            inputGBK.go:296-299): one (key, proteinId) per 7-mer window;     */
+/*   build  = indexdb.IndexStore/KeyToList (indexdb.go:68-132) +               */
+/*            RemoveDuplicatesFromSlice (kv_store.go:284-305): per key the     */
+/*            unique id set; identical sets are stored once (the KComb idea,   */
+/*            kcomb_store.go:42-85).                                           */
+/* An image is the host copy of one shard's table (buckets + postings arena).  */
+/* ------------------------------------------------------------------------- */
+typedef struct { uint32_t key; uint32_t protein_id; } kaamer_pair;
+typedef struct kaamer_image kaamer_image;
+
+typedef struct {
+    uint64_t n_pairs;      /* unique (key,id) pairs in this shard              */
+    uint64_t n_keys;       /* distinct keys in this shard                      */
+    uint64_t n_buckets;    /* 64-byte buckets                                  */
+    uint64_t arena_words;  /* u32 words of the postings arena                  */
+    uint64_t n_inline;     /* keys whose single id is stored in the slot       */
+    uint64_t n_lists;      /* distinct postings lists in the arena             */
+    uint64_t max_list;     /* longest postings list                            */
+    uint64_t n_displaced;  /* keys not in their home bucket                    */
+    uint32_t shard, n_shards;
+    uint32_t max_protein_id;
+    uint32_t reserved;
+} kaamer_image_stats;
+
+/* shard s of n_shards holds the keys with kaamer_shard_of(key) == s */
+uint32_t kaamer_shard_of(uint32_t key, uint32_t n_shards);
+
+int kaamer_image_build_pairs(const kaamer_pair *pairs, uint64_t n, uint32_t shard,
+                             uint32_t n_shards, double load_factor, kaamer_image **out);
+/* Emit loop + build: every window seqs[off[p]+i .. +7), i in [0,len-7], of
+ * every protein with len >= 7, under id ids[p] (ids == NULL: the TSV rule,
+ * 0-based running index, inputTSV.go:141-142). */
+int kaamer_image_build_proteins(const uint8_t *seqs, const uint64_t *offsets,
+                                const uint32_t *ids, uint32_t n_proteins, uint32_t shard,
+                                uint32_t n_shards, double load_factor, kaamer_image **out);
+int kaamer_image_save(const kaamer_image *img, const char *path);
+int kaamer_image_load(const char *path, kaamer_image **out);
+int kaamer_image_get_stats(const kaamer_image *img, kaamer_image_stats *out);
+void kaamer_image_free(kaamer_image *img);
+/* host-side point read of an image (builder self-check; not the search path):
+ * returns the number of ids under `key`, copies up to cap of them */
+uint32_t kaamer_image_get(const kaamer_image *img, uint32_t key, uint32_t *ids, uint32_t cap);
+
+/* ------------------------------------------------------------------------- */
+/* Index handle — replaces the read side of kvstore.KVStoresNew               */
+/* (kv_stores.go:46-104) and KVStore.GetValueFromBadger (kv_store.go:179-204): */
+/* the table lives in the HBM of one device.                                   */
+/* ------------------------------------------------------------------------- */
+typedef struct kaamer_index kaamer_index;
+
+int kaamer_index_open_image(const kaamer_image *img, int device, kaamer_index **out);
+int kaamer_index_open(const char *path, int device, kaamer_index **out);
+void kaamer_index_close(kaamer_index *ix);
+int kaamer_index_get_stats(const kaamer_index *ix, kaamer_image_stats *out);
+
+/* ------------------------------------------------------------------------- */
+/* Search — replaces, per query, the block keyChan / KmerSearch /              */
+/* StoreMatchPositions / sortMapByValue (search_protein.go:78-105,             */
+/* search_fastq.go:94-118, search_nucleotide.go:91-115; search.go:414-452) and,*/
+/* for nucleotide input, the preceding GetORFs call (dna.go:65-181;            */
+/* search_fastq.go:74, search_nucleotide.go:136).                              */
+/* ------------------------------------------------------------------------- */
+
+/* One query handed to KmerSearch: a protein record, or one ORF of a read.     */
+typedef struct {
+    uint32_t src_seq;        /* index of the input sequence it came from       */
+    int32_t size_in_kmer;    /* Query.SizeInKmer (search.go:290-293)           */
+    int32_t start_position;  /* Location (dna.go:35-40); proteins: 1           */
+    int32_t end_position;    /*                          proteins: len         */
+    int32_t plus_strand;
+    uint32_t aa_len;         /* residues of Query.Sequence                     */
+    uint64_t aa_off;         /* into orf_aa (reads) / the input seqs (protein) */
+    uint32_t sa_off, sa_len; /* Location.StartsAlternative, into starts_alt    */
+} kaamer_query_meta;
+
+/* Exact work counters of one batch, counted by the kernels themselves.        */
+typedef struct {
+    uint64_t n_in;       /* input bytes read (residues / nucleotides)          */
+    uint64_t n_queries;  /* queries searched (proteins, or ORFs)               */
+    uint64_t n_lookup;   /* k-mer lookups = KeyPos handed to KmerSearch        */
+    uint64_t n_probe;    /* 64-byte buckets inspected (>= n_lookup)            */
+    uint64_t n_found;    /* lookups whose key is present                       */
+    uint64_t n_post;     /* postings expanded = sum |index[key]| over found    */
+    uint64_t n_hits;     /* (query, protein) result pairs                      */
+    uint64_t n_overflow; /* queries that left the on-chip counting tier        */
+    uint64_t n_lists;    /* found lookups resolved through an arena list       */
+                         /* (the others carry their single id in the slot)     */
+    uint64_t n_list_ids; /* protein ids read from arena lists (<= n_post)      */
+} kaamer_counters;
+
+typedef struct {
+    const uint8_t *seqs;      /* packed sequences, caller-owned                */
+    const uint64_t *offsets;  /* n_seqs + 1                                    */
+    uint32_t n_seqs;
+    int32_t seq_type;         /* KAAMER_NUCLEOTIDE / PROTEIN / READS           */
+    int32_t want_positions;   /* SearchOptions.ExtractPositions (search.go:64) */
+} kaamer_batch_in;
+
+typedef struct {
+    uint32_t n_queries;
+    const kaamer_query_meta *q;
+    const uint64_t *hit_off;     /* CSR over queries, n_queries + 1            */
+    const uint32_t *hit_pid;     /* Hit.Key      (search.go:111-115)           */
+    const uint32_t *hit_kmatch;  /* Hit.Kmatch; unsorted within a query        */
+    const uint32_t *hit_first_pos; /* lowest query position that matched the   */
+                                 /* hit: all SetBestStartCodon needs           */
+                                 /* (dna.go:225-237)                           */
+    const uint64_t *pos_off;     /* per hit, word offset into pos_bits; NULL   */
+    const uint64_t *pos_bits;    /* PositionHits bitmaps (search.go:442-452),  */
+                                 /* size_in_kmer bits per hit; NULL unless     */
+                                 /* want_positions                             */
+    const uint8_t *orf_aa;       /* reads/nucleotide: ORF amino-acid strings   */
+    const int32_t *starts_alt;
+    kaamer_counters counters;
+} kaamer_batch_out;
+
+int kaamer_search_batch(kaamer_index *ix, const kaamer_batch_in *in, kaamer_batch_out **out);
+void kaamer_batch_free(kaamer_batch_out *out);
+
+/* ------------------------------------------------------------------------- */
+/* Device-resident form of the same call: inputs already in HBM, results left  */
+/* in HBM, everything enqueued on the caller's HIP stream, no host sync.       */
+/* (Used by bench.py and by callers that pipeline batches; `stream` is a       */
+/* hipStream_t passed as void*.)                                               */
+/* ------------------------------------------------------------------------- */
+typedef struct kaamer_workspace kaamer_workspace;
+
+typedef struct {
+    uint64_t max_seq_bytes;  /* largest packed input batch                     */
+    uint32_t max_seqs;       /* most input sequences per batch                 */
+    uint32_t max_queries;    /* most queries (ORFs) per batch; 0 = derive      */
+    uint64_t max_hits;       /* most (query,protein) pairs per batch; 0=derive */
+    uint32_t lds_slots;      /* on-chip counting table slots per query         */
+                             /* (power of two, 64..4096); 0 = default          */
+    uint32_t reserved;
+} kaamer_workspace_opts;
+
+typedef struct {
+    uint32_t n_queries_cap;
+    const uint32_t *d_n_queries;        /* device scalar                       */
+    const kaamer_query_meta *d_q;
+    const uint64_t *d_hit_off;          /* n_queries + 1                       */
+    const uint32_t *d_hit_pid;
+    const uint32_t *d_hit_kmatch;
+    const uint32_t *d_hit_first_pos;
+    const uint8_t *d_orf_aa;
+    const int32_t *d_starts_alt;
+    const kaamer_counters *d_counters;  /* device copy, valid after the stream */
+} kaamer_device_result;
+
+int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
+                            kaamer_workspace **out);
+void kaamer_workspace_free(kaamer_workspace *ws);
+int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *d_seqs,
+                         const uint64_t *d_offsets, uint32_t n_seqs, uint64_t seq_bytes,
+                         int32_t seq_type, void *stream, kaamer_device_result *out);
+/* Waits for `stream`, copies the counters to the host and reports a deferred
+ * KAAMER_E_CAPACITY if a device-side bound was exceeded during the batch. */
+int kaamer_workspace_finish(kaamer_workspace *ws, void *stream, kaamer_counters *out);
+/* HIP-event time (ms) of the dominant kernel (the k-mer probe/count kernel) of
+ * the most recent kaamer_search_device call on this workspace, measured on the
+ * stream it was launched on.  Valid after kaamer_workspace_finish. */
+int kaamer_workspace_last_kernel_ms(kaamer_workspace *ws, float *search_ms, float *total_ms);
+/* Sums of the same two HIP-event times over the kaamer_search_device calls made
+ * on this workspace since the previous kaamer_workspace_reset_timers (at most
+ * 1024 calls are kept).  The stream must have been synchronised. */
+int kaamer_workspace_kernel_ms_sum(kaamer_workspace *ws, double *search_ms, double *total_ms,
+                                   uint32_t *n_calls);
+void kaamer_workspace_reset_timers(kaamer_workspace *ws);
+
+/* ------------------------------------------------------------------------- */
+/* Host post-steps kept bit-compatible with the reference (they stay on the    */
+/* host in the Go integration; exported so non-Go callers get the same         */
+/* results).                                                                   */
+/* ------------------------------------------------------------------------- */
+/* QueryResult.FilterResults, search.go:189-220: hits sorted by Kmatch desc;
+ * returns how many (a prefix) survive MinKRatio / MinKMatch / MaxResults.     */
+int64_t kaamer_filter_results(const uint32_t *kmatch_sorted, int64_t n_hits, int32_t size_in_kmer,
+                              double min_k_ratio, int64_t min_k_match, int64_t max_results);
+/* sortMapByValue, search.go:132-152: order hit indices by Kmatch descending;
+ * ties (nondeterministic in the reference) are broken by ascending protein id. */
+void kaamer_sort_hits(const uint32_t *pid, const uint32_t *kmatch, int64_t n_hits, uint32_t *order);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KAAMER_HIP_H */

@@ -1,0 +1,136 @@
+"""ctypes binding of libkaamer_hip.so — one Python declaration per symbol of
+include/kaamer_hip.h.  Loading fails loudly if the library has not been built
+(`python -m kaamer_amd.build`); there is no fallback implementation.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkaamer_hip.so")
+
+OK, E_ARG, E_IO, E_NOMEM, E_HIP, E_CAPACITY, E_FORMAT = 0, -1, -2, -3, -4, -5, -6
+NUCLEOTIDE, PROTEIN, READS = 0, 1, 2
+
+
+class KaamerError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("kaamer_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Pair(C.Structure):
+    _fields_ = [("key", C.c_uint32), ("protein_id", C.c_uint32)]
+
+
+class ImageStats(C.Structure):
+    _fields_ = [("n_pairs", C.c_uint64), ("n_keys", C.c_uint64), ("n_buckets", C.c_uint64),
+                ("arena_words", C.c_uint64), ("n_inline", C.c_uint64), ("n_lists", C.c_uint64),
+                ("max_list", C.c_uint64), ("n_displaced", C.c_uint64), ("shard", C.c_uint32),
+                ("n_shards", C.c_uint32), ("max_protein_id", C.c_uint32), ("reserved", C.c_uint32)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}
+
+
+class QueryMeta(C.Structure):
+    _fields_ = [("src_seq", C.c_uint32), ("size_in_kmer", C.c_int32), ("start_position", C.c_int32),
+                ("end_position", C.c_int32), ("plus_strand", C.c_int32), ("aa_len", C.c_uint32),
+                ("aa_off", C.c_uint64), ("sa_off", C.c_uint32), ("sa_len", C.c_uint32)]
+
+
+class Counters(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("n_in", "n_queries", "n_lookup", "n_probe", "n_found",
+                                          "n_post", "n_hits", "n_overflow", "n_lists", "n_list_ids")]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class BatchIn(C.Structure):
+    _fields_ = [("seqs", C.c_void_p), ("offsets", C.c_void_p), ("n_seqs", C.c_uint32),
+                ("seq_type", C.c_int32), ("want_positions", C.c_int32)]
+
+
+class BatchOut(C.Structure):
+    _fields_ = [("n_queries", C.c_uint32), ("q", C.POINTER(QueryMeta)),
+                ("hit_off", C.POINTER(C.c_uint64)), ("hit_pid", C.POINTER(C.c_uint32)),
+                ("hit_kmatch", C.POINTER(C.c_uint32)), ("hit_first_pos", C.POINTER(C.c_uint32)),
+                ("pos_off", C.POINTER(C.c_uint64)), ("pos_bits", C.POINTER(C.c_uint64)),
+                ("orf_aa", C.POINTER(C.c_uint8)), ("starts_alt", C.POINTER(C.c_int32)),
+                ("counters", Counters)]
+
+
+class WorkspaceOpts(C.Structure):
+    _fields_ = [("max_seq_bytes", C.c_uint64), ("max_seqs", C.c_uint32), ("max_queries", C.c_uint32),
+                ("max_hits", C.c_uint64), ("lds_slots", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class DeviceResult(C.Structure):
+    _fields_ = [("n_queries_cap", C.c_uint32), ("d_n_queries", C.c_void_p), ("d_q", C.c_void_p),
+                ("d_hit_off", C.c_void_p), ("d_hit_pid", C.c_void_p), ("d_hit_kmatch", C.c_void_p),
+                ("d_hit_first_pos", C.c_void_p), ("d_orf_aa", C.c_void_p), ("d_starts_alt", C.c_void_p),
+                ("d_counters", C.c_void_p)]
+
+
+# every symbol include/kaamer_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "kaamer_last_error": (C.c_char_p, []),
+    "kaamer_abi_version": (C.c_int, []),
+    "kaamer_encode_kmer": (C.c_uint32, [C.c_char_p]),
+    "kaamer_shard_of": (C.c_uint32, [C.c_uint32, C.c_uint32]),
+    "kaamer_image_build_pairs": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_double,
+                                           C.POINTER(C.c_void_p)]),
+    "kaamer_image_build_proteins": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                              C.c_uint32, C.c_double, C.POINTER(C.c_void_p)]),
+    "kaamer_image_save": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "kaamer_image_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "kaamer_image_get_stats": (C.c_int, [C.c_void_p, C.POINTER(ImageStats)]),
+    "kaamer_image_free": (None, [C.c_void_p]),
+    "kaamer_image_get": (C.c_uint32, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]),
+    "kaamer_index_open_image": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "kaamer_index_open": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "kaamer_index_close": (None, [C.c_void_p]),
+    "kaamer_index_get_stats": (C.c_int, [C.c_void_p, C.POINTER(ImageStats)]),
+    "kaamer_search_batch": (C.c_int, [C.c_void_p, C.POINTER(BatchIn), C.POINTER(C.POINTER(BatchOut))]),
+    "kaamer_batch_free": (None, [C.POINTER(BatchOut)]),
+    "kaamer_workspace_create": (C.c_int, [C.c_void_p, C.POINTER(WorkspaceOpts), C.POINTER(C.c_void_p)]),
+    "kaamer_workspace_free": (None, [C.c_void_p]),
+    "kaamer_search_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                       C.c_uint64, C.c_int32, C.c_void_p, C.POINTER(DeviceResult)]),
+    "kaamer_workspace_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Counters)]),
+    "kaamer_workspace_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "kaamer_workspace_kernel_ms_sum": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                                 C.POINTER(C.c_uint32)]),
+    "kaamer_workspace_reset_timers": (None, [C.c_void_p]),
+    "kaamer_filter_results": (C.c_int64, [C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_int64, C.c_int64]),
+    "kaamer_sort_hits": (None, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Loads libkaamer_hip.so.  `import torch` first when torch is used in the same
+    process, so both resolve to ONE HIP runtime (same libamdhip64 SONAME)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libkaamer_hip.so is not built: run `python -m kaamer_amd.build` "
+                          "(expected at %s); there is no CPU fallback" % LIB_PATH)
+    try:
+        import torch  # noqa: F401  (loads torch's libamdhip64 first when torch is installed)
+    except Exception:
+        pass
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        f = getattr(L, name)  # AttributeError if the library lacks a declared symbol
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != OK:
+        raise KaamerError(rc, (lib().kaamer_last_error() or b"").decode("utf-8", "replace"))

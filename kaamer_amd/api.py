@@ -1,0 +1,223 @@
+"""Python plumbing over the C ABI: builds images from numpy buffers, opens an
+index on a device, and runs batches either from host buffers or from
+torch-owned device tensors (device memory and streams are torch's job here,
+nothing else).  All compute happens inside libkaamer_hip.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+
+
+def pack_sequences(seqs):
+    """list of bytes/str -> (uint8 array, uint64 offsets[n+1])"""
+    bs = [s.encode("latin-1") if isinstance(s, str) else bytes(s) for s in seqs]
+    offs = np.zeros(len(bs) + 1, dtype=np.uint64)
+    if bs:
+        offs[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+    buf = np.frombuffer(b"".join(bs), dtype=np.uint8).copy() if bs else np.zeros(0, np.uint8)
+    return buf, offs
+
+
+class Image:
+    """Host copy of one shard's table (the builder's output)."""
+
+    def __init__(self, handle):
+        self._h = C.c_void_p(handle)
+
+    @classmethod
+    def from_pairs(cls, keys, ids, shard=0, n_shards=1, load_factor=0.5):
+        keys = np.ascontiguousarray(keys, dtype=np.uint32)
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        pairs = np.empty((len(keys), 2), dtype=np.uint32)
+        pairs[:, 0] = keys
+        pairs[:, 1] = ids
+        h = C.c_void_p()
+        abi.check(abi.lib().kaamer_image_build_pairs(pairs.ctypes.data, len(keys), shard, n_shards,
+                                                     load_factor, C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def from_proteins(cls, seqs=None, ids=None, packed=None, shard=0, n_shards=1, load_factor=0.5):
+        buf, offs = packed if packed is not None else pack_sequences(seqs)
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        idp = None
+        if ids is not None:
+            ids = np.ascontiguousarray(ids, dtype=np.uint32)
+            idp = ids.ctypes.data
+        h = C.c_void_p()
+        abi.check(abi.lib().kaamer_image_build_proteins(buf.ctypes.data, offs.ctypes.data, idp,
+                                                        len(offs) - 1, shard, n_shards, load_factor,
+                                                        C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def load(cls, path):
+        h = C.c_void_p()
+        abi.check(abi.lib().kaamer_image_load(str(path).encode(), C.byref(h)))
+        return cls(h.value)
+
+    def save(self, path):
+        abi.check(abi.lib().kaamer_image_save(self._h, str(path).encode()))
+
+    def stats(self):
+        s = abi.ImageStats()
+        abi.check(abi.lib().kaamer_image_get_stats(self._h, C.byref(s)))
+        return s.as_dict()
+
+    def get(self, key):
+        n = abi.lib().kaamer_image_get(self._h, int(key), None, 0)
+        out = np.zeros(n, dtype=np.uint32)
+        if n:
+            abi.lib().kaamer_image_get(self._h, int(key), out.ctypes.data, n)
+        return out
+
+    def close(self):
+        if self._h:
+            abi.lib().kaamer_image_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def build_image_from_proteins(seqs, ids=None, **kw):
+    return Image.from_proteins(seqs, ids=ids, **kw)
+
+
+class BatchResult:
+    """Host view of one kaamer_batch_out (copied out, the C object is freed)."""
+
+    def __init__(self, out):
+        o = out.contents
+        n = o.n_queries
+        self.n_queries = n
+        meta = np.ctypeslib.as_array(C.cast(o.q, C.POINTER(C.c_uint8)), shape=(n * C.sizeof(abi.QueryMeta),)).copy() \
+            if n else np.zeros(0, np.uint8)
+        self.meta = meta.view(np.dtype([("src_seq", "<u4"), ("size_in_kmer", "<i4"), ("start_position", "<i4"),
+                                        ("end_position", "<i4"), ("plus_strand", "<i4"), ("aa_len", "<u4"),
+                                        ("aa_off", "<u8"), ("sa_off", "<u4"), ("sa_len", "<u4")]))
+        self.hit_off = np.ctypeslib.as_array(o.hit_off, shape=(n + 1,)).copy()
+        nh = int(self.hit_off[n])
+        z = np.zeros(0, np.uint32)
+        self.hit_pid = np.ctypeslib.as_array(o.hit_pid, shape=(nh,)).copy() if nh else z
+        self.hit_kmatch = np.ctypeslib.as_array(o.hit_kmatch, shape=(nh,)).copy() if nh else z
+        self.hit_first_pos = np.ctypeslib.as_array(o.hit_first_pos, shape=(nh,)).copy() if nh else z
+        self.counters = o.counters.as_dict()
+        aa_len = int((self.meta["aa_off"] + self.meta["aa_len"]).max()) if n and bool(o.orf_aa) else 0
+        self.orf_aa = np.ctypeslib.as_array(o.orf_aa, shape=(aa_len,)).copy() if aa_len else np.zeros(0, np.uint8)
+        sa_len = int((self.meta["sa_off"] + self.meta["sa_len"]).max()) if n and bool(o.starts_alt) else 0
+        self.starts_alt = np.ctypeslib.as_array(o.starts_alt, shape=(sa_len,)).copy() if sa_len else np.zeros(0, np.int32)
+
+    def hits(self, q):
+        """{protein id: Kmatch} of query q (the parity object: SURVEY §2.1)."""
+        a, b = int(self.hit_off[q]), int(self.hit_off[q + 1])
+        return dict(zip(self.hit_pid[a:b].tolist(), self.hit_kmatch[a:b].tolist()))
+
+    def first_pos(self, q):
+        a, b = int(self.hit_off[q]), int(self.hit_off[q + 1])
+        return dict(zip(self.hit_pid[a:b].tolist(), self.hit_first_pos[a:b].tolist()))
+
+
+class Index:
+    """The table resident in one device's HBM."""
+
+    def __init__(self, handle, device):
+        self._h = C.c_void_p(handle)
+        self.device = device
+
+    @classmethod
+    def from_image(cls, image, device=0):
+        h = C.c_void_p()
+        abi.check(abi.lib().kaamer_index_open_image(image._h, device, C.byref(h)))
+        return cls(h.value, device)
+
+    @classmethod
+    def open(cls, path, device=0):
+        h = C.c_void_p()
+        abi.check(abi.lib().kaamer_index_open(str(path).encode(), device, C.byref(h)))
+        return cls(h.value, device)
+
+    def stats(self):
+        s = abi.ImageStats()
+        abi.check(abi.lib().kaamer_index_get_stats(self._h, C.byref(s)))
+        return s.as_dict()
+
+    def search(self, seqs=None, packed=None, seq_type=abi.PROTEIN, want_positions=False):
+        """Host-buffer form (kaamer_search_batch)."""
+        buf, offs = packed if packed is not None else pack_sequences(seqs)
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        bi = abi.BatchIn(buf.ctypes.data if len(buf) else None, offs.ctypes.data, len(offs) - 1, seq_type,
+                         int(want_positions))
+        out = C.POINTER(abi.BatchOut)()
+        abi.check(abi.lib().kaamer_search_batch(self._h, C.byref(bi), C.byref(out)))
+        try:
+            return BatchResult(out)
+        finally:
+            abi.lib().kaamer_batch_free(out)
+
+    def close(self):
+        if self._h:
+            abi.lib().kaamer_index_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Workspace:
+    """Reusable device buffers for the device-resident call."""
+
+    def __init__(self, index, max_seq_bytes, max_seqs, max_queries=0, max_hits=0, lds_slots=0):
+        self.index = index
+        o = abi.WorkspaceOpts(max_seq_bytes, max_seqs, max_queries, max_hits, lds_slots, 0)
+        h = C.c_void_p()
+        abi.check(abi.lib().kaamer_workspace_create(index._h, C.byref(o), C.byref(h)))
+        self._h = h
+
+    def search_device(self, d_seqs_ptr, d_offsets_ptr, n_seqs, seq_bytes, seq_type=abi.PROTEIN, stream=0):
+        """Enqueue one batch; pointers are raw device addresses (e.g. tensor.data_ptr()),
+        `stream` a raw hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)."""
+        r = abi.DeviceResult()
+        abi.check(abi.lib().kaamer_search_device(self.index._h, self._h, d_seqs_ptr, d_offsets_ptr, n_seqs,
+                                                 seq_bytes, seq_type, C.c_void_p(stream), C.byref(r)))
+        return r
+
+    def finish(self, stream=0):
+        c = abi.Counters()
+        abi.check(abi.lib().kaamer_workspace_finish(self._h, C.c_void_p(stream), C.byref(c)))
+        return c.as_dict()
+
+    def last_kernel_ms(self):
+        a, b = C.c_float(), C.c_float()
+        abi.check(abi.lib().kaamer_workspace_last_kernel_ms(self._h, C.byref(a), C.byref(b)))
+        return float(a.value), float(b.value)
+
+    def kernel_ms_sum(self):
+        """(search kernel ms, whole-batch ms, calls) summed since reset_timers()."""
+        a, b, n = C.c_double(), C.c_double(), C.c_uint32()
+        abi.check(abi.lib().kaamer_workspace_kernel_ms_sum(self._h, C.byref(a), C.byref(b), C.byref(n)))
+        return float(a.value), float(b.value), int(n.value)
+
+    def reset_timers(self):
+        abi.lib().kaamer_workspace_reset_timers(self._h)
+
+    def close(self):
+        if self._h:
+            abi.lib().kaamer_workspace_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,148 @@
+"""CPU-side checks of the product library: it loads, exports every symbol the
+header declares, and its host logic (builder, codec, filter) agrees with the
+oracle.  No device calls here."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "kaamer_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(kaamer_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(klib):
+    from kaamer_amd import abi
+    names = _declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(klib, n), "libkaamer_hip.so lacks %s" % n
+    assert sorted(abi.SYMBOLS) == names, "abi.py and include/kaamer_hip.h disagree"
+    assert klib.kaamer_abi_version() == 1
+
+
+def test_product_does_not_use_the_oracle():
+    """No file of the product may import/link/execute anything under oracle/."""
+    for d, _, files in os.walk(os.path.join(ROOT, "kaamer_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(d, f), errors="replace").read()
+                assert "oracle" not in txt.lower(), os.path.join(d, f)
+
+
+def test_codec_host_matches_oracle(klib, oracle):
+    import random
+    rng = random.Random(2)
+    alpha = "ACDEFGHIKLMNPQRSTUVWYBJOXZ*a-"
+    for _ in range(5000):
+        k = "".join(rng.choice(alpha) for _ in range(7)).encode()
+        assert klib.kaamer_encode_kmer(k) == oracle.encode_kmer(k)
+    for b in range(256):
+        k = bytes([b]) * 7
+        assert klib.kaamer_encode_kmer(k) == oracle.encode_kmer(k)
+
+
+@pytest.mark.parametrize("n_shards", [1, 2, 8])
+def test_builder_image_equals_oracle_index(klib, oracle, n_shards):
+    from kaamer_amd import api, workload
+    db = workload.make_db(300, seed=5)
+    oi = oracle.Index.from_proteins(None, packed=db)
+    pairs = oi.pairs()
+    keys = np.unique(pairs >> 32).astype(np.uint32)
+    imgs = [api.Image.from_proteins(packed=db, shard=s, n_shards=n_shards) for s in range(n_shards)]
+    st = [im.stats() for im in imgs]
+    assert sum(s["n_pairs"] for s in st) == len(pairs)
+    assert sum(s["n_keys"] for s in st) == len(keys)
+    rng = np.random.default_rng(0)
+    for k in rng.choice(keys, 3000, replace=False):
+        s = klib.kaamer_shard_of(int(k), n_shards)
+        got = np.sort(imgs[s].get(int(k)))
+        assert np.array_equal(got, oi.get(int(k)))
+        for t in range(n_shards):
+            if t != s:
+                assert len(imgs[t].get(int(k))) == 0
+    for k in (0, 1, 0x12345678, 0xE773B9D4, 0xFFFFFFFE):
+        if k not in keys:
+            assert all(len(im.get(k)) == 0 for im in imgs)
+
+
+def test_builder_pairs_dedup_and_sharing(klib, oracle):
+    from kaamer_amd import api
+    # duplicates (makedb writes one version per window; indexdb de-duplicates: kv_store.go:284-305)
+    keys = np.array([5, 5, 5, 9, 9, 7, 7, 7, 7, 11, 12, 12], dtype=np.uint32)
+    ids = np.array([3, 3, 1, 2, 2, 4, 1, 4, 3, 0x80000005, 1, 3], dtype=np.uint32)
+    img = api.Image.from_pairs(keys, ids)
+    assert sorted(img.get(5).tolist()) == [1, 3]
+    assert img.get(9).tolist() == [2]
+    assert sorted(img.get(7).tolist()) == [1, 3, 4]
+    assert img.get(11).tolist() == [0x80000005]          # id >= 2^31 cannot be stored inline
+    assert sorted(img.get(12).tolist()) == [1, 3]
+    st = img.stats()
+    assert st["n_pairs"] == 9 and st["n_keys"] == 5 and st["n_inline"] == 1
+    assert st["n_lists"] == 3                             # {1,3} stored once, shared by keys 5 and 12
+    oi = oracle.Index.from_pairs(keys, ids)
+    for k in (5, 7, 9, 11, 12, 13):
+        assert np.array_equal(np.sort(img.get(k)), oi.get(k))
+
+
+def test_builder_rejects_reserved_values(klib):
+    from kaamer_amd import abi, api
+    with pytest.raises(abi.KaamerError):
+        api.Image.from_pairs([0xFFFFFFFF], [1])
+    with pytest.raises(abi.KaamerError):
+        api.Image.from_pairs([1], [0xFFFFFFFF])
+
+
+def test_image_save_load_roundtrip(klib, tmp_path):
+    from kaamer_amd import abi, api, workload
+    db = workload.make_db(50, seed=9)
+    img = api.Image.from_proteins(packed=db)
+    p = tmp_path / "db.kaamerht"
+    img.save(p)
+    img2 = api.Image.load(p)
+    assert img.stats() == img2.stats()
+    k = int(klib.kaamer_encode_kmer(bytes(db[0][:7])))
+    assert np.array_equal(img.get(k), img2.get(k)) and len(img.get(k)) >= 1
+    bad = tmp_path / "bad"
+    bad.write_bytes(b"\0" * 8192)
+    with pytest.raises(abi.KaamerError) as e:
+        api.Image.load(bad)
+    assert e.value.code == abi.E_FORMAT
+    with pytest.raises(abi.KaamerError) as e:
+        api.Image.load(tmp_path / "missing")
+    assert e.value.code == abi.E_IO
+
+
+def test_filter_and_sort_match_oracle(klib, oracle):
+    import random
+    rng = random.Random(4)
+    for _ in range(300):
+        n = rng.randint(0, 30)
+        size = rng.randint(7, 400)
+        pid = np.array(rng.sample(range(10000), n), dtype=np.uint32)
+        km = np.array([rng.randint(1, size) for _ in range(n)], dtype=np.uint32)
+        order = np.zeros(n, dtype=np.uint32)
+        klib.kaamer_sort_hits(pid.ctypes.data, km.ctypes.data, n, order.ctypes.data)
+        exp = sorted(range(n), key=lambda i: (-int(km[i]), int(pid[i])))
+        assert order.tolist() == exp
+        kms = np.ascontiguousarray(km[order])
+        for opts in ((0.05, 10, 10), (0.3, 1, 5), (0.0, 0, 100)):
+            assert klib.kaamer_filter_results(kms.ctypes.data, n, size, *opts) == \
+                oracle.filter_results(kms.astype(np.int64), size, *opts)
+
+
+def test_no_gpu_fails_loudly(klib):
+    """Without a device the index cannot open: an error, never a CPU fallback."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from kaamer_amd import abi, api, workload
+    img = api.Image.from_proteins(packed=workload.make_db(20, seed=1))
+    with pytest.raises(abi.KaamerError) as e:
+        api.Index.from_image(img, 0)
+    assert e.value.code == abi.E_HIP

@@ -1,0 +1,210 @@
+"""GPU parity tests of the protein path: the HIP kernels (through the C ABI)
+against the CPU oracle, bit-exact on {protein id -> Kmatch} per query."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _oracle_hits(oix, oracle, seqs):
+    out = []
+    for s in seqs:
+        size = oracle.size_in_kmer(s)
+        if size < 7:                       # search_protein.go:74-76
+            out.append(({}, {}))
+            continue
+        pid, km, pos = oix.search(s, want_positions=True)
+        first = {int(p): int(np.argmax(pos[i])) for i, p in enumerate(pid)}
+        out.append((dict(zip(pid.tolist(), km.tolist())), first))
+    return out
+
+
+def _check(res, exp):
+    assert res.n_queries == len(exp)
+    for q, (hits, first) in enumerate(exp):
+        assert res.hits(q) == hits, "query %d" % q
+        assert res.first_pos(q) == first, "query %d first positions" % q
+
+
+@pytest.fixture(scope="module")
+def small(klib, oracle, gpu_device):
+    """BASELINE config 1: DB-S (1000 proteins) + 100 protein queries."""
+    from kaamer_amd import api, workload
+    db = workload.make_db(1000)
+    img = api.Image.from_proteins(packed=db)
+    ix = api.Index.from_image(img, gpu_device)
+    oix = oracle.Index.from_proteins(None, packed=db)
+    return db, img, ix, oix
+
+
+def test_config1_parity(small, oracle):
+    from kaamer_amd import workload
+    db, img, ix, oix = small
+    q = workload.make_protein_queries(db, 100)
+    res = ix.search(packed=q)
+    exp = _oracle_hits(oix, oracle, workload.unpack(q))
+    _check(res, exp)
+    c = res.counters
+    assert c["n_queries"] == 100
+    assert c["n_lookup"] == sum(oracle.size_in_kmer(s) for s in workload.unpack(q))
+    assert c["n_hits"] == sum(len(h) for h, _ in exp)
+    assert c["n_probe"] >= c["n_lookup"] and c["n_found"] <= c["n_lookup"] and c["n_overflow"] == 0
+    # Σ_p Kmatch(p) = Σ_pos |index[key(pos)]| = n_post
+    assert c["n_post"] == sum(sum(h.values()) for h, _ in exp)
+    # meta: SizeInKmer / Location as GetQueriesFasta sets them (search.go:290-294)
+    seqs = workload.unpack(q)
+    assert res.meta["size_in_kmer"].tolist() == [oracle.size_in_kmer(s) for s in seqs]
+    assert res.meta["end_position"].tolist() == [len(s) for s in seqs]
+    assert (res.meta["start_position"] == 1).all() and (res.meta["plus_strand"] == 1).all()
+
+
+def test_self_hits(small, oracle):
+    """every DB protein queried against its own DB scores len-6 on itself (docs/client.md:120-156)"""
+    from kaamer_amd import workload
+    db, img, ix, oix = small
+    seqs = workload.unpack(db)[:200]
+    res = ix.search(seqs)
+    for q, s in enumerate(seqs):
+        assert res.hits(q)[q] == len(s) - 6
+        assert res.first_pos(q)[q] == 0
+
+
+def test_docs_worked_example(klib, oracle, gpu_device):
+    from kaamer_amd import api
+    ex = json.load(open(os.path.join(GOLD, "docs_example.json")))
+    img = api.Image.from_proteins([ex["db_sequence"]], ids=[ex["hit_key"]])
+    ix = api.Index.from_image(img, gpu_device)
+    res = ix.search([ex["query"]])
+    assert int(res.meta["size_in_kmer"][0]) == ex["size_in_kmer"]
+    assert res.hits(0) == {ex["hit_key"]: ex["kmatch"]}
+    assert (int(res.meta["start_position"][0]), int(res.meta["end_position"][0])) == (1, ex["end_position"])
+
+
+def test_edge_cases(small, oracle):
+    from kaamer_amd import workload
+    db, img, ix, oix = small
+    base = workload.unpack(db)
+    seqs = [b"", b"A", b"AAAAAA", b"AAAAAAA", base[0][:12], base[0][:13], base[0][:13] + b"*",
+            base[0][:14] + b"*", base[1] + b"*", base[2].lower(), b"X" * 40, b"*" * 30,
+            base[3][:64 + 6], base[3][:65 + 6], base[3][:63 + 6], base[4][:128 + 6], base[4][:129 + 6],
+            base[5][:20] + b"XX" + base[5][22:], bytes(range(256)) * 2, base[6] * 3,
+            max(base, key=len), min(base, key=len)]
+    res = ix.search(seqs)
+    _check(res, _oracle_hits(oix, oracle, seqs))
+    assert res.hits(0) == {} and res.hits(4) == {}          # SizeInKmer < 7 -> no result
+    assert res.hits(5) != {}                                # 13 aa -> SizeInKmer 7
+
+
+def test_empty_batch(small):
+    db, img, ix, oix = small
+    res = ix.search([])
+    assert res.n_queries == 0 and len(res.hit_pid) == 0 and res.hit_off.tolist() == [0]
+
+
+def test_ragged_many_queries(small, oracle):
+    """more queries than resident waves, ragged lengths, every chunk boundary"""
+    from kaamer_amd import workload
+    db, img, ix, oix = small
+    rng = np.random.default_rng(8)
+    base = workload.unpack(db)
+    seqs = []
+    for i in range(3000):
+        s = base[int(rng.integers(0, len(base)))]
+        a = int(rng.integers(0, max(1, len(s) - 13)))
+        n = int(rng.integers(0, 200))
+        seqs.append(s[a:a + n])
+    res = ix.search(seqs)
+    _check(res, _oracle_hits(oix, oracle, seqs))
+
+
+def test_shared_kmers_long_lists(klib, oracle, gpu_device):
+    """postings lists longer than the in-lane limit take the wave-cooperative path"""
+    from kaamer_amd import api
+    rng = np.random.default_rng(3)
+    alpha = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
+    core = bytes(alpha[rng.integers(0, 20, 40)])
+    db = [bytes(alpha[rng.integers(0, 20, 10)]) + core[: 10 + (i % 31)] + bytes(alpha[rng.integers(0, 20, 10)])
+          for i in range(300)]
+    ids = (np.arange(300) * 7 + 11).astype(np.uint32)
+    img = api.Image.from_proteins(db, ids=ids)
+    assert img.stats()["max_list"] >= 200
+    ix = api.Index.from_image(img, gpu_device)
+    oix = oracle.Index.from_proteins(db, ids=ids)
+    seqs = [core, db[0], db[150], core[5:30], b"AAAAAAAAAAAAAAAA"]
+    res = ix.search(seqs)
+    _check(res, _oracle_hits(oix, oracle, seqs))
+
+
+def test_counting_table_overflow_is_reported(klib, gpu_device):
+    """a query that exceeds the on-chip table must raise, never return partial counts"""
+    from kaamer_amd import abi, api
+    import torch
+    rng = np.random.default_rng(4)
+    alpha = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
+    core = bytes(alpha[rng.integers(0, 20, 30)])
+    db = [core for _ in range(200)]                         # 200 proteins share every k-mer
+    img = api.Image.from_proteins(db)
+    ix = api.Index.from_image(img, gpu_device)
+    buf, offs = api.pack_sequences([core])
+    d_buf = torch.from_numpy(buf).cuda()
+    d_off = torch.from_numpy(offs.view(np.int64)).cuda()
+    ws = api.Workspace(ix, len(buf), 1, lds_slots=64)       # 64 slots < 200 distinct proteins
+    ws.search_device(d_buf.data_ptr(), d_off.data_ptr(), 1, len(buf), stream=torch.cuda.current_stream().cuda_stream)
+    with pytest.raises(abi.KaamerError) as e:
+        ws.finish(torch.cuda.current_stream().cuda_stream)
+    assert e.value.code == abi.E_CAPACITY
+    ws2 = api.Workspace(ix, len(buf), 1, lds_slots=512)
+    ws2.search_device(d_buf.data_ptr(), d_off.data_ptr(), 1, len(buf), stream=torch.cuda.current_stream().cuda_stream)
+    c = ws2.finish(torch.cuda.current_stream().cuda_stream)
+    assert c["n_hits"] == 200 and c["n_overflow"] == 0
+
+
+def test_device_resident_call_and_reuse(small, oracle):
+    """torch owns the device buffers and the stream; the workspace is reused across batches"""
+    import ctypes as C
+    import torch
+    from kaamer_amd import api, workload
+    db, img, ix, oix = small
+    stream = torch.cuda.Stream()
+    ws = api.Workspace(ix, 1 << 20, 500)
+    for seed in (1, 2, 3):
+        q = workload.make_protein_queries(db, 300, seed=seed)
+        buf, offs = q
+        with torch.cuda.stream(stream):
+            d_buf = torch.from_numpy(buf).cuda()
+            d_off = torch.from_numpy(offs.view(np.int64)).cuda()
+            r = ws.search_device(d_buf.data_ptr(), d_off.data_ptr(), 300, len(buf), stream=stream.cuda_stream)
+            c = ws.finish(stream.cuda_stream)
+        exp = _oracle_hits(oix, oracle, workload.unpack(q))
+        n_hits = sum(len(h) for h, _ in exp)
+        assert c["n_hits"] == n_hits
+
+        # read results back through torch from the raw device pointers
+        hit_off = _from_ptr(r.d_hit_off, 301, np.uint64)
+        pid = _from_ptr(r.d_hit_pid, n_hits, np.uint32)
+        km = _from_ptr(r.d_hit_kmatch, n_hits, np.uint32)
+        for qi, (hits, _) in enumerate(exp):
+            a, b = int(hit_off[qi]), int(hit_off[qi + 1])
+            assert dict(zip(pid[a:b].tolist(), km[a:b].tolist())) == hits
+        ms_search, ms_total = ws.last_kernel_ms()
+        assert 0 < ms_search <= ms_total
+
+
+def _from_ptr(ptr, n, dtype):
+    """copy n items of dtype from a raw device pointer (hipMemcpy through the HIP runtime torch loaded)"""
+    import ctypes as C
+    import torch
+    out = np.empty(n, dtype=dtype)
+    if n == 0:
+        return out
+    hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    torch.cuda.synchronize()
+    rc = hip.hipMemcpy(out.ctypes.data, C.c_void_p(ptr), out.nbytes, 2)
+    assert rc == 0
+    return out
