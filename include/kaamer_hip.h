@@ -188,9 +188,13 @@ typedef struct {
     uint32_t max_seqs;       /* most input sequences per batch                 */
     uint32_t max_queries;    /* most queries (ORFs) per batch; 0 = derive      */
     uint64_t max_hits;       /* most (query,protein) pairs per batch; 0=derive */
-    uint32_t lds_slots;      /* on-chip counting table slots per query         */
-                             /* (power of two, 64..4096); 0 = default          */
-    uint32_t reserved;
+    uint32_t lds_slots;      /* S-tier on-chip counting table slots per query  */
+                             /* (power of two, 64..2048); 0 = default 512      */
+    uint32_t s_tier_max_kmers; /* queries up to this SizeInKmer run one wave   */
+                             /* per query, longer ones a 16-wave workgroup;    */
+                             /* 0 = default                                    */
+    uint64_t g_tier_slots;   /* HBM counting-table slots for queries whose     */
+                             /* distinct hits exceed the on-chip tiers; 0 = def*/
 } kaamer_workspace_opts;
 
 typedef struct {
@@ -215,15 +219,15 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
 /* Waits for `stream`, copies the counters to the host and reports a deferred
  * KAAMER_E_CAPACITY if a device-side bound was exceeded during the batch. */
 int kaamer_workspace_finish(kaamer_workspace *ws, void *stream, kaamer_counters *out);
-/* HIP-event time (ms) of the dominant kernel (the k-mer probe/count kernel) of
- * the most recent kaamer_search_device call on this workspace, measured on the
- * stream it was launched on.  Valid after kaamer_workspace_finish. */
-int kaamer_workspace_last_kernel_ms(kaamer_workspace *ws, float *search_ms, float *total_ms);
-/* Sums of the same two HIP-event times over the kaamer_search_device calls made
- * on this workspace since the previous kaamer_workspace_reset_timers (at most
- * 1024 calls are kept).  The stream must have been synchronised. */
-int kaamer_workspace_kernel_ms_sum(kaamer_workspace *ws, double *search_ms, double *total_ms,
-                                   uint32_t *n_calls);
+/* HIP-event times (ms), measured on the stream the kernels were launched on and
+ * summed over the kaamer_search_device calls made on this workspace since the
+ * previous kaamer_workspace_reset_timers (at most 1024 calls are kept):
+ *   probe_ms  the probe kernel (the dominant kernel: one 64-B bucket per lookup)
+ *   count_ms  the counting tiers (postings expansion + per-protein counting)
+ *   total_ms  the whole batch, prep to CSR
+ * The stream must have been synchronised (kaamer_workspace_finish does). */
+int kaamer_workspace_kernel_ms_sum(kaamer_workspace *ws, double *probe_ms, double *count_ms,
+                                   double *total_ms, uint32_t *n_calls);
 void kaamer_workspace_reset_timers(kaamer_workspace *ws);
 
 /* ------------------------------------------------------------------------- */

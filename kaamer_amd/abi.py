@@ -62,7 +62,8 @@ class BatchOut(C.Structure):
 
 class WorkspaceOpts(C.Structure):
     _fields_ = [("max_seq_bytes", C.c_uint64), ("max_seqs", C.c_uint32), ("max_queries", C.c_uint32),
-                ("max_hits", C.c_uint64), ("lds_slots", C.c_uint32), ("reserved", C.c_uint32)]
+                ("max_hits", C.c_uint64), ("lds_slots", C.c_uint32), ("s_tier_max_kmers", C.c_uint32),
+                ("g_tier_slots", C.c_uint64)]
 
 
 class DeviceResult(C.Structure):
@@ -98,9 +99,8 @@ SYMBOLS = {
     "kaamer_search_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                        C.c_uint64, C.c_int32, C.c_void_p, C.POINTER(DeviceResult)]),
     "kaamer_workspace_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Counters)]),
-    "kaamer_workspace_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "kaamer_workspace_kernel_ms_sum": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
-                                                 C.POINTER(C.c_uint32)]),
+                                                 C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
     "kaamer_workspace_reset_timers": (None, [C.c_void_p]),
     "kaamer_filter_results": (C.c_int64, [C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_int64, C.c_int64]),
     "kaamer_sort_hits": (None, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -177,9 +177,11 @@ class Index:
 class Workspace:
     """Reusable device buffers for the device-resident call."""
 
-    def __init__(self, index, max_seq_bytes, max_seqs, max_queries=0, max_hits=0, lds_slots=0):
+    def __init__(self, index, max_seq_bytes, max_seqs, max_queries=0, max_hits=0, lds_slots=0,
+                 s_tier_max_kmers=0, g_tier_slots=0):
         self.index = index
-        o = abi.WorkspaceOpts(max_seq_bytes, max_seqs, max_queries, max_hits, lds_slots, 0)
+        o = abi.WorkspaceOpts(max_seq_bytes, max_seqs, max_queries, max_hits, lds_slots, s_tier_max_kmers,
+                              g_tier_slots)
         h = C.c_void_p()
         abi.check(abi.lib().kaamer_workspace_create(index._h, C.byref(o), C.byref(h)))
         self._h = h
@@ -197,16 +199,11 @@ class Workspace:
         abi.check(abi.lib().kaamer_workspace_finish(self._h, C.c_void_p(stream), C.byref(c)))
         return c.as_dict()
 
-    def last_kernel_ms(self):
-        a, b = C.c_float(), C.c_float()
-        abi.check(abi.lib().kaamer_workspace_last_kernel_ms(self._h, C.byref(a), C.byref(b)))
-        return float(a.value), float(b.value)
-
     def kernel_ms_sum(self):
-        """(search kernel ms, whole-batch ms, calls) summed since reset_timers()."""
-        a, b, n = C.c_double(), C.c_double(), C.c_uint32()
-        abi.check(abi.lib().kaamer_workspace_kernel_ms_sum(self._h, C.byref(a), C.byref(b), C.byref(n)))
-        return float(a.value), float(b.value), int(n.value)
+        """dict(probe_ms, count_ms, total_ms, calls) summed since reset_timers()."""
+        a, b, c, n = C.c_double(), C.c_double(), C.c_double(), C.c_uint32()
+        abi.check(abi.lib().kaamer_workspace_kernel_ms_sum(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
+        return dict(probe_ms=float(a.value), count_ms=float(b.value), total_ms=float(c.value), calls=int(n.value))
 
     def reset_timers(self):
         abi.lib().kaamer_workspace_reset_timers(self._h)

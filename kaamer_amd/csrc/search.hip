@@ -3,24 +3,29 @@
 // What runs on the device, per batch (all on the caller's stream, no host sync):
 //
 //   prep_protein_kernel   Query.SizeInKmer etc. for protein records
-//                         (search.go:290-293; search_protein.go:70-76)
-//   kmer_search_kernel    THE hot loop: sliding 7-mer encode (k_store.go:91-117,
+//                         (search.go:290-293; search_protein.go:70-76) and the
+//                         tier work lists
+//   lds_tier_kernel       THE hot loop: sliding 7-mer encode (k_store.go:91-117,
 //                         search_protein.go:94-98), bucket probe (replaces the
 //                         two Badger point reads of search.go:421-429), postings
 //                         expansion and per-protein counting (search.go:431-436,
 //                         442-452) in an LDS hash table, ballot/prefix-sum
-//                         compaction of the hit list
+//                         compaction of the hit list.  Two instantiations:
+//                           S tier: one wave per query (short queries)
+//                           L tier: one 16-wave workgroup per query (long
+//                                   queries and S-tier overflows), 4096 slots
+//   global_tier_kernel    G tier: queries whose distinct hits exceed the L table
+//                         count into an exactly sized table in HBM
 //   scan / gather kernels hit lists -> CSR in query order
 //
-// One wavefront (64 lanes) owns one query at a time; a workgroup is exactly one
-// wave, so __syncthreads() is a wave-local fence and waves never wait for each
-// other.  This is integer hashing/indexing: no MFMA; the bound is HBM (random
-// 64-byte bucket reads + postings).
+// This is integer hashing/indexing: no MFMA; the bound is HBM (random 64-byte
+// bucket reads + postings).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -58,323 +63,766 @@ struct kaamer_index {
     uint32_t *d_arena;
 };
 
-enum { ST_POOL_FULL = 1u, ST_OVF_LIST_FULL = 2u, ST_QUERY_CAP = 4u, ST_AA_CAP = 8u, ST_OVERFLOW_UNSERVED = 16u };
+enum { ST_POOL_FULL = 1u, ST_LIST_FULL = 2u, ST_QUERY_CAP = 4u, ST_AA_CAP = 8u, ST_G_ARENA_FULL = 16u, ST_G_TABLE_FULL = 32u };
 enum { CTR_IN = 0, CTR_QUERIES, CTR_LOOKUP, CTR_PROBE, CTR_FOUND, CTR_POST, CTR_HITS, CTR_OVERFLOW, CTR_LISTS, CTR_LIST_IDS, CTR_N };
 static_assert(sizeof(kaamer_counters) == CTR_N * 8, "counter layout");
 #define CTR_REPLICAS 64
 
-struct SearchParams {
-    const uint4 *table;  // buckets viewed as 4 x uint4 each
-    uint64_t n_buckets;
-    uint32_t n_shards, shard;
-    const uint32_t *arena;
-    const uint8_t *residues;  // input seqs (protein) or ORF amino acids (reads)
-    const kaamer_query_meta *q;
-    const uint32_t *d_nq;
-    int32_t min_size;  // search_protein.go:74: protein queries with SizeInKmer < 7 are dropped
-    // per-query result location in the pool
-    uint64_t *q_start;
-    uint32_t *q_cnt;
-    uint32_t *pool_pid, *pool_km, *pool_fp;
-    uint64_t pool_cap;
-    unsigned long long *pool_cursor;
-    uint32_t *ovf_list;
-    uint32_t *ovf_count;
-    uint32_t ovf_cap;
-    unsigned long long *counters;  // [CTR_REPLICAS][CTR_N]
-    uint32_t *status;
+// work lists of the counting tiers (device memory)
+enum { LIST_S = 0, LIST_L, LIST_SO, LIST_G, N_LISTS };
+// one entry: everything a tier needs to start on a query, in one 16-byte load
+struct alignas(16) WorkItem {
+    uint32_t q;
+    int32_t size;     // SizeInKmer
+    uint64_t aa_off;  // first residue position of the query
 };
 
-#define POOL_CHUNK 1024u
+#define POOL_CHUNK 256u
+// The hit pool is split into POOL_SHARDS regions, each with its own bump cursor on its own
+// cache line: one shared cursor word serialises the whole grid behind the L2 atomic unit
+// (~88 atomics/us on one address).
+#define POOL_SHARDS 64u
+#define CURSOR_STRIDE 32u  /* unsigned long long words between cursors (256 B) */
 #define MAX_TIMED_CALLS 1024u
-#define COOP_LIST_THRESHOLD 48u
+#define L_WAVES 8
+#define L_LOG2CAP 12
+#define G_WAVES 16
+#ifndef S_NWIN
+#define S_NWIN 3
+#endif
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 
-__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v)
+__device__ __forceinline__ uint32_t wave_sum32(uint32_t v)
 {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
-
-// LDS counting table: open addressing keyed by protein id.
-template <int LOG2CAP>
-__device__ __forceinline__ bool table_add(volatile uint32_t *keys, uint32_t *cnt, uint32_t *minpos,
-                                          uint32_t *nd, uint32_t pid, uint32_t pos)
+// wave total as a scalar (uniform) value
+__device__ __forceinline__ uint32_t wave_total(uint32_t v)
 {
-    constexpr uint32_t MASK = (1u << LOG2CAP) - 1u;
-    uint32_t h = (pid * 0x9E3779B1u) >> (32 - LOG2CAP);
-    for (uint32_t t = 0; t <= MASK; t++) {
-        uint32_t k = keys[h];
-        if (k == KH_EMPTY_PID) {
-            uint32_t old = atomicCAS((uint32_t *)&keys[h], KH_EMPTY_PID, pid);
-            if (old == KH_EMPTY_PID) { atomicAdd(nd, 1u); k = pid; }
-            else k = old;
-        }
-        if (k == pid) {
-            atomicAdd(&cnt[h], 1u);
-            atomicMin(&minpos[h], pos);
-            return true;
-        }
-        h = (h + 1u) & MASK;
-    }
-    return false;
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_sum32(v));
 }
 
-template <int LOG2CAP>
-__global__ __launch_bounds__(64) void kmer_search_kernel(SearchParams p)
+__device__ __forceinline__ void add_counter(unsigned long long *replicas, uint32_t replica, int which, unsigned long long v)
+{
+    if (v) atomicAdd(&replicas[(size_t)(replica % CTR_REPLICAS) * CTR_N + which], v);
+}
+
+// ====================================================================================
+// Kernel P — flat probe over residue positions
+// ====================================================================================
+// Position i of the packed residue buffer is a k-mer start iff bit (i & 63) of
+// valid[i >> 6] is set (prep clears the tail of every query and whole queries that are
+// too short).  One wave handles 64 consecutive positions: residue codes are staged in
+// LDS, each lane encodes its 7-mer (k_store.go:91-117 in closed form), then the wave
+// probes the bucket table with 4 lanes per 64-byte bucket (16 B each, one fabric
+// sector per probe) and writes one u32 per position:
+//     vals[i] = 0            key absent (or position not a k-mer start)
+//             = slot.val     key present: inline protein id or postings-list offset
+// This replaces KmerStore.GetValueFromBadger (search.go:421) for the whole batch at
+// once; the work is perfectly balanced whatever the query lengths are.
+struct ProbeParams {
+    const uint4 *table;  // buckets viewed as 4 x uint4 each
+    uint64_t n_buckets;
+    uint32_t n_shards, shard;
+    const uint8_t *residues;
+    unsigned long long *invalid;  // one bit per position, set = not a k-mer start; self-cleaning
+    const unsigned long long *d_n_pos;  // device scalar: number of residue positions
+    uint32_t *vals;
+    unsigned long long *counters;
+};
+
+#define P_WAVES 4
+
+__global__ __launch_bounds__(64 * P_WAVES) void probe_kernel(ProbeParams p)
+{
+    __shared__ uint8_t s_lut[256];
+    __shared__ uint8_t s_stage[P_WAVES][80];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const unsigned long long n_pos = *p.d_n_pos;
+    const unsigned long long n_win = (n_pos + 63) >> 6;
+    for (uint32_t i = tid; i < 256; i += 64 * P_WAVES) s_lut[i] = (uint8_t)kh_residue_code((uint8_t)i);
+    uint32_t c_lookup = 0, c_probe = 0, c_found = 0;
+
+    for (unsigned long long w0 = (unsigned long long)blockIdx.x * P_WAVES; w0 < n_win; w0 += (unsigned long long)gridDim.x * P_WAVES) {
+        const unsigned long long w = w0 + wv;
+        const bool live = w < n_win;
+        const unsigned long long base = w << 6;
+        unsigned long long mask = 0ull;
+        if (live) {
+            mask = ~p.invalid[w];
+            if (lane == 0 && mask != ~0ull) p.invalid[w] = 0ull;  // leave the bitmap clean for the next batch
+        }
+        __syncthreads();  // stage reuse + LUT ready
+        if (mask) {
+            const unsigned long long i0 = base + lane;
+            s_stage[wv][lane] = (i0 < n_pos) ? s_lut[p.residues[i0]] : (uint8_t)KH_CODE_UNKNOWN;
+            if (lane < 6) s_stage[wv][64 + lane] = (i0 + 64 < n_pos) ? s_lut[p.residues[i0 + 64]] : (uint8_t)KH_CODE_UNKNOWN;
+        }
+        __syncthreads();
+        uint32_t key = KH_EMPTY_KEY;
+        if ((mask >> lane) & 1ull) {
+            const uint8_t *st = s_stage[wv] + lane;
+            key = kh_key_from_codes(st[0], st[1], st[2], st[3], st[4], st[5], st[6]);
+            // sharded index: this device probes only the keys it owns
+            if (p.n_shards > 1 && kh_shard_of(key, p.n_shards) != p.shard) key = KH_EMPTY_KEY;
+        }
+        const uint32_t bucket = (key != KH_EMPTY_KEY) ? (uint32_t)kh_home_bucket(key, p.n_shards, p.n_buckets) : 0u;
+
+        // round j serves the k-mers of lanes 16j..16j+15; lane 4g+j ends up owning k-mer 16j+g
+        uint4 ld[4];
+        uint32_t rkey[4], rb[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int src = 16 * j + (int)(lane >> 2);
+            rb[j] = __shfl(bucket, src, 64);
+            rkey[j] = __shfl(key, src, 64);
+            ld[j] = make_uint4(KH_EMPTY_KEY, 0, KH_EMPTY_KEY, 0);
+            if (rkey[j] != KH_EMPTY_KEY) ld[j] = p.table[(uint64_t)rb[j] * 4 + (lane & 3u)];
+        }
+        uint32_t okey = KH_EMPTY_KEY, oval = 0, obucket = 0;
+        bool oempty = true;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t kk = rkey[j];
+            uint32_t r = (ld[j].x == kk) ? ld[j].y : ((ld[j].z == kk) ? ld[j].w : 0u);
+            uint32_t e = (ld[j].x == KH_EMPTY_KEY || ld[j].z == KH_EMPTY_KEY) ? 1u : 0u;
+            r |= __shfl_xor(r, 1, 64); e |= __shfl_xor(e, 1, 64);
+            r |= __shfl_xor(r, 2, 64); e |= __shfl_xor(e, 2, 64);
+            if ((lane & 3u) == (uint32_t)j) { okey = kk; oval = r; oempty = (e != 0u); obucket = rb[j]; }
+        }
+        const bool valid = okey != KH_EMPTY_KEY;
+        if (valid) { c_lookup++; c_probe++; }
+        // rare: home bucket full and key not in it -> this lane walks the following buckets alone
+        if (valid && oval == 0u && !oempty) {
+            for (uint64_t tries = 1; tries < p.n_buckets; tries++) {
+                obucket = (obucket + 1u == (uint32_t)p.n_buckets) ? 0u : obucket + 1u;
+                c_probe++;
+                bool e = false;
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    const uint4 v = p.table[(uint64_t)obucket * 4 + s];
+                    if (v.x == okey) oval = v.y;
+                    if (v.z == okey) oval = v.w;
+                    e = e || v.x == KH_EMPTY_KEY || v.z == KH_EMPTY_KEY;
+                }
+                if (oval != 0u || e) break;
+            }
+        }
+        if (valid && oval != 0u) c_found++;
+        // the owner lane writes the position it owns: 16*(lane&3) + (lane>>2)
+        const unsigned long long opos = base + 16u * (lane & 3u) + (lane >> 2);
+        if (live && opos < n_pos) p.vals[opos] = valid ? oval : 0u;
+    }
+    const uint32_t t_lookup = wave_total(c_lookup), t_probe = wave_total(c_probe), t_found = wave_total(c_found);
+    if (lane == 0) {
+        const uint32_t rep = blockIdx.x * P_WAVES + wv;
+        add_counter(p.counters, rep, CTR_LOOKUP, t_lookup);
+        add_counter(p.counters, rep, CTR_PROBE, t_probe);
+        add_counter(p.counters, rep, CTR_FOUND, t_found);
+    }
+}
+
+// ====================================================================================
+// Kernel H — flat fetch of the postings heads
+// ====================================================================================
+// Position-parallel again: heads[i] = {count, id0, id1, id2} of the k-mer at position i
+// (count 0: absent; inline single: {1, id}); lists longer than three ids keep their
+// remaining ids in the arena at vals[i]*16 + 16.  Moves the random 16-byte head reads out
+// of the per-query chain into a balanced, fully occupied kernel.
+__global__ __launch_bounds__(256) void heads_kernel(const uint32_t *vals, const uint32_t *arena,
+                                                    const unsigned long long *d_n_pos, uint4 *heads)
+{
+    const unsigned long long n_pos = *d_n_pos;
+    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_pos;
+         i += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint32_t v = vals[i];
+        uint4 h = make_uint4(0, 0, 0, 0);
+        if (v & KH_INLINE_BIT) h = make_uint4(1u, v & ~KH_INLINE_BIT, 0, 0);
+        else if (v != 0u) h = reinterpret_cast<const uint4 *>(arena)[v];
+        heads[i] = h;
+    }
+}
+
+// ====================================================================================
+// Kernel C — per-query counting (postings expansion + Counter increments)
+// ====================================================================================
+struct CountParams {
+    const uint32_t *arena;
+    const uint32_t *vals;  // from kernel P, indexed like the residue buffer
+    const uint4 *heads;    // from kernel H: {count, id0, id1, id2} per position
+    // tier input / overflow output lists
+    const WorkItem *list;
+    const uint32_t *list_count;
+    WorkItem *ovf_list;
+    uint32_t *ovf_count;
+    uint32_t list_cap;
+    uint32_t *queue_head;  // dynamic dequeue for the S tier
+    // per-query result location in the pool
+    uint64_t *q_start;
+    uint32_t *q_cnt;
+    uint32_t *pool_pid, *pool_km, *pool_fp;
+    uint64_t pool_shard_cap;          // entries per shard region
+    unsigned long long *pool_cursor;  // [POOL_SHARDS] cursors, CURSOR_STRIDE apart, relative to the shard base
+    // G tier arena
+    uint32_t *g_keys, *g_cnt, *g_min;
+    uint64_t g_slots;
+    unsigned long long *g_cursor;
+    uint32_t n_proteins;
+    unsigned long long *counters;  // [CTR_REPLICAS][CTR_N]
+    uint32_t *status;
+    uint32_t ablate;  // timing experiments only (KAAMER_ABLATE): 1 no table adds, 2 no leftover loads, 4 no hit stores
+};
+
+// counting tables: protein id -> (count, lowest matching position)
+template <int LOG2CAP> struct LdsTable {
+    volatile uint32_t *keys;
+    uint32_t *cnt, *minpos, *nd;
+    static constexpr uint32_t CAP = 1u << LOG2CAP;
+    static constexpr uint32_t LIMIT = CAP - CAP / 4;  // keep 25 % free
+    uint32_t ablate;
+    // n matches of `pid`, the lowest of them at `pos`.  `nnew` counts the entries this lane
+    // created: the distinct-hit counter is updated once per wave, not once per insertion
+    // (64 lanes bumping one LDS word serialise).
+    __device__ __forceinline__ bool add_n(uint32_t pid, uint32_t pos, uint32_t n, uint32_t &nnew) const
+    {
+        if (ablate & 1u) { asm volatile("" ::"v"(pid), "v"(pos), "v"(n)); return true; }
+        constexpr uint32_t MASK = CAP - 1u;
+        uint32_t h = (pid * 0x9E3779B1u) >> (32 - LOG2CAP);
+        for (uint32_t t = 0; t <= MASK; t++) {
+            uint32_t k = keys[h];
+            if (k == KH_EMPTY_PID) {
+                const uint32_t old = atomicCAS((uint32_t *)&keys[h], KH_EMPTY_PID, pid);
+                if (old == KH_EMPTY_PID) { nnew++; k = pid; }
+                else k = old;
+            }
+            if (k == pid) {
+                if (!(ablate & 8u)) {
+                    atomicAdd(&cnt[h], n);
+                    atomicMin(&minpos[h], pos);
+                }
+                return true;
+            }
+            h = (h + 1u) & MASK;
+        }
+        return false;
+    }
+    __device__ __forceinline__ bool over_limit() const { return *(volatile uint32_t *)nd > LIMIT; }
+};
+
+struct GlobalTable {
+    uint32_t *keys, *cnt, *minpos, *nd;  // nd lives in LDS
+    uint32_t log2cap;
+    __device__ __forceinline__ bool add_n(uint32_t pid, uint32_t pos, uint32_t n, uint32_t &nnew) const
+    {
+        const uint32_t mask = (1u << log2cap) - 1u;
+        uint32_t h = (pid * 0x9E3779B1u) >> (32 - log2cap);
+        for (uint32_t t = 0; t <= mask; t++) {
+            uint32_t k = __hip_atomic_load(&keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (k == KH_EMPTY_PID) {
+                const uint32_t old = atomicCAS(&keys[h], KH_EMPTY_PID, pid);
+                if (old == KH_EMPTY_PID) { nnew++; k = pid; }
+                else k = old;
+            }
+            if (k == pid) {
+                atomicAdd(&cnt[h], n);
+                atomicMin(&minpos[h], pos);
+                return true;
+            }
+            h = (h + 1u) & mask;
+        }
+        return false;
+    }
+    __device__ __forceinline__ bool over_limit() const { return false; }
+};
+
+struct PostCtr {
+    uint32_t post, lists, lids;
+    __device__ void clear() { post = lists = lids = 0; }
+};
+
+// Adjacent positions of a query mostly hit the same proteins (a homologous stretch), so
+// lane i and lane i+1 usually carry the same id in the same head slot.  Sixty-four lanes
+// adding to one LDS word serialise; instead the first lane of every run of equal ids adds
+// the whole run at once (run length from a ballot of the change points).
+template <class Table>
+__device__ __forceinline__ bool add_runs(const Table &tab, uint32_t x, uint32_t pos, uint32_t &nnew)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t prev = __shfl_up(x, 1, 64);
+    const bool change = (lane == 0) || (prev != x);
+    const unsigned long long cm = __ballot(change);
+    bool ok = true;
+    if (change && x != KH_EMPTY_PID) {
+        const unsigned long long above = (lane == 63) ? 0ull : (cm >> (lane + 1));
+        const uint32_t len = above ? (uint32_t)__ffsll((long long)above) : 64u - lane;
+        ok = tab.add_n(x, pos, len, nnew);
+    }
+    return ok;
+}
+
+// NWIN 64-position windows of one query, processed by one wave with all their memory
+// round trips overlapped: (1) the probe results of every window, (2) the 16-byte heads of
+// every postings list (count + first three ids), (3) the remaining ids of all lists,
+// spread evenly over the 64 lanes whatever the individual list lengths are (per-window
+// prefix sum of the leftovers, owner found by binary search in LDS), then the counter
+// increments (KCombStore.Get + the id loop of search.go:427-436).  Window k starts at
+// c0 + k*stride.  `s_pref` is 64 words of LDS private to the wave.  No workgroup
+// barriers inside.  COUNT_ONLY: only sum the postings (G tier sizing pass).
+template <class Table, int NWIN, bool COUNT_ONLY>
+__device__ __forceinline__ bool count_windows(const CountParams &p, const uint32_t *vals, const uint4 *heads,
+                                              int32_t size, int32_t c0, int32_t stride, const Table &tab, PostCtr &c,
+                                              volatile uint32_t *s_pref)
+{
+    const uint32_t lane = lane_id();
+    uint32_t v[NWIN];
+    uint4 h[NWIN];
+#pragma unroll
+    for (int k = 0; k < NWIN; k++) {
+        const int32_t pos = c0 + k * stride + (int32_t)lane;
+        v[k] = 0u;
+        h[k] = make_uint4(0, 0, 0, 0);
+        if (pos < size) { v[k] = vals[pos]; h[k] = heads[pos]; }
+    }
+    bool ok = true;
+    uint32_t nnew = 0;
+    // leftovers (ids beyond the three that came with the head): all their loads are issued
+    // before anything is consumed
+    constexpr int XIT = 2;  // leftover rounds kept in registers per window (64 ids each)
+    uint32_t xid[NWIN][XIT], xpos[NWIN][XIT];
+    uint32_t xtotal[NWIN];
+    if (!COUNT_ONLY) {
+#pragma unroll
+        for (int k = 0; k < NWIN; k++) {
+            const uint32_t lcnt = h[k].x;
+            const uint32_t extra = lcnt > 3u ? lcnt - 3u : 0u;
+            uint32_t inc = extra;  // inclusive prefix over the wave
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = __shfl_up(inc, o, 64);
+                if ((int)lane >= o) inc += t;
+            }
+            xtotal[k] = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            s_pref[k * 64 + lane] = inc - extra;  // exclusive prefix
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < NWIN; k++) {
+            const volatile uint32_t *pref = s_pref + k * 64;
+#pragma unroll
+            for (int it = 0; it < XIT; it++) {
+                const uint32_t t = (uint32_t)it * 64u + lane;
+                const bool act = t < xtotal[k] && !(p.ablate & 2u);
+                uint32_t lo = 0;
+                if (act) {  // largest lane with pref[lane] <= t owns leftover t
+#pragma unroll
+                    for (int sft = 32; sft > 0; sft >>= 1)
+                        if (pref[lo + sft] <= t) lo += sft;
+                }
+                // executed by all lanes: the owner may be a lane that is idle in this round
+                const uint32_t off = __shfl(v[k], (int)lo, 64);
+                xid[k][it] = KH_EMPTY_PID;
+                xpos[k][it] = (uint32_t)(c0 + k * stride) + lo;
+                if (act) xid[k][it] = p.arena[(uint64_t)off * 4 + 4 + (t - pref[lo])];
+            }
+        }
+        // very long lists (more than XIT*64 leftovers in one window): counted as they arrive
+#pragma unroll
+        for (int k = 0; k < NWIN; k++) {
+            const volatile uint32_t *pref = s_pref + k * 64;
+            for (uint32_t t0 = XIT * 64u; t0 < xtotal[k]; t0 += 64) {
+                const uint32_t t = t0 + lane;
+                const bool act = t < xtotal[k];
+                uint32_t lo = 0;
+                if (act) {
+#pragma unroll
+                    for (int sft = 32; sft > 0; sft >>= 1)
+                        if (pref[lo + sft] <= t) lo += sft;
+                }
+                const uint32_t off = __shfl(v[k], (int)lo, 64);
+                if (act) ok = ok && tab.add_n(p.arena[(uint64_t)off * 4 + 4 + (t - pref[lo])], (uint32_t)(c0 + k * stride) + lo, 1u, nnew);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // heads: inline ids and the first three ids of every list
+#pragma unroll
+    for (int k = 0; k < NWIN; k++) {
+        const uint32_t pos = (uint32_t)(c0 + k * stride) + lane;
+        const uint32_t lcnt = h[k].x;
+        if (lcnt != 0u) {
+            c.post += lcnt;
+            if (!(v[k] & KH_INLINE_BIT)) { c.lists++; c.lids += lcnt; }
+        }
+        if (!COUNT_ONLY) {  // all lanes take part: run heads add for their whole run
+            ok = add_runs(tab, lcnt > 0 ? h[k].y : KH_EMPTY_PID, pos, nnew) && ok;
+            ok = add_runs(tab, lcnt > 1 ? h[k].z : KH_EMPTY_PID, pos, nnew) && ok;
+            ok = add_runs(tab, lcnt > 2 ? h[k].w : KH_EMPTY_PID, pos, nnew) && ok;
+        }
+    }
+    if (!COUNT_ONLY) {
+#pragma unroll
+        for (int k = 0; k < NWIN; k++)
+#pragma unroll
+            for (int it = 0; it < XIT; it++)
+                if (xid[k][it] != KH_EMPTY_PID) ok = ok && tab.add_n(xid[k][it], xpos[k][it], 1u, nnew);
+        const uint32_t wave_new = wave_total(nnew);
+        if (lane == 0 && wave_new) atomicAdd(tab.nd, wave_new);
+    }
+    return __all(ok);
+}
+
+// ---- S and L tiers: counting table in LDS ---------------------------------------------------------
+//   S: WAVES = 1, one wave per query, items pulled from a queue
+//   L: WAVES = 8, one workgroup per query (long queries, S-tier overflows)
+template <int LOG2CAP, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void count_lds_kernel(CountParams p)
 {
     constexpr int CAP = 1 << LOG2CAP;
-    constexpr uint32_t CAP_LIMIT = (uint32_t)(CAP - CAP / 4);  // leave 25 % free
+    constexpr int STRIPES = CAP / 64;
+    static_assert(STRIPES <= 64, "stripe prefix uses one wave");
     __shared__ uint32_t t_keys[CAP];
     __shared__ uint32_t t_cnt[CAP];
     __shared__ uint32_t t_min[CAP];
-    __shared__ uint8_t s_lut[256];
-    __shared__ uint8_t s_stage[128];
     __shared__ uint32_t s_nd, s_ovf;
+    __shared__ uint32_t s_stripe[STRIPES];
+    constexpr int NWIN = (WAVES == 1) ? S_NWIN : 2;  // windows in flight per wave
+    __shared__ uint32_t s_pref[WAVES][NWIN * 64];
+    __shared__ unsigned long long s_base;
 
-    const uint32_t lane = lane_id();
-    const uint32_t wave = blockIdx.x;
-    const uint32_t n_waves = gridDim.x;
-    const uint32_t nq = *p.d_nq;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint32_t n_items = *p.list_count < p.list_cap ? *p.list_count : p.list_cap;
 
-    for (uint32_t i = lane; i < 256; i += 64) s_lut[i] = (uint8_t)kh_residue_code((uint8_t)i);
+    LdsTable<LOG2CAP> tab;
+    tab.keys = t_keys; tab.cnt = t_cnt; tab.minpos = t_min; tab.nd = &s_nd; tab.ablate = p.ablate;
 
-    unsigned long long c_in = 0, c_q = 0, c_lookup = 0, c_probe = 0, c_found = 0, c_post = 0, c_hits = 0, c_ovf = 0, c_lists = 0, c_lids = 0;
+    unsigned long long tot_in = 0, tot_q = 0, tot_post = 0, tot_hits = 0, tot_ovf = 0, tot_lists = 0, tot_lids = 0;
+    PostCtr pc;
     uint64_t chunk_base = 0;
     uint32_t chunk_left = 0;
 
-    for (uint32_t q = wave; q < nq; q += n_waves) {
-        const kaamer_query_meta qm = p.q[q];
-        const int32_t size = qm.size_in_kmer;
-        if (size < p.min_size || size <= 0) {
-            if (lane == 0) { p.q_cnt[q] = 0; p.q_start[q] = 0; }
-            continue;
-        }
-        const uint8_t *res = p.residues + qm.aa_off;
-        for (uint32_t i = lane; i < (uint32_t)CAP; i += 64) { t_keys[i] = KH_EMPTY_PID; t_cnt[i] = 0; t_min[i] = 0xFFFFFFFFu; }
-        if (lane == 0) { s_nd = 0; s_ovf = 0; }
+    uint32_t item = blockIdx.x;
+    while (item < n_items) {
+        const WorkItem wi = p.list[item];
+        const uint32_t q = wi.q;
+        const int32_t size = wi.size;
+        const uint32_t *vals = p.vals + wi.aa_off;
+        const uint4 *heads = p.heads + wi.aa_off;
+        for (uint32_t i = tid; i < (uint32_t)CAP; i += 64 * WAVES) { t_keys[i] = KH_EMPTY_PID; t_cnt[i] = 0; t_min[i] = 0xFFFFFFFFu; }
+        if (tid == 0) { s_nd = 0; s_ovf = 0; }
+        pc.clear();
         __syncthreads();
-        if (lane == 0) { c_q++; c_in += (unsigned long long)size + 6; }
 
         bool overflow = false;
-        for (int32_t c0 = 0; c0 < size && !overflow; c0 += 64) {
-            const int32_t n_here = min(64, size - c0);
-            // stage residue codes of this window: n_here + 6 residues
-            if ((int32_t)lane < n_here + 6) s_stage[lane] = s_lut[res[c0 + lane]];
-            if ((int32_t)lane + 64 < n_here + 6) s_stage[lane + 64] = s_lut[res[c0 + 64 + lane]];
-            __syncthreads();
-            uint32_t key = KH_EMPTY_KEY;
-            if ((int32_t)lane < n_here)
-                key = kh_key_from_codes(s_stage[lane], s_stage[lane + 1], s_stage[lane + 2], s_stage[lane + 3],
-                                        s_stage[lane + 4], s_stage[lane + 5], s_stage[lane + 6]);
-            // sharded index: this device probes only the keys it owns
-            if (p.n_shards > 1 && key != KH_EMPTY_KEY && kh_shard_of(key, p.n_shards) != p.shard) key = KH_EMPTY_KEY;
-            uint32_t bucket = (key != KH_EMPTY_KEY) ? (uint32_t)kh_home_bucket(key, p.n_shards, p.n_buckets) : 0u;
-
-            // ---- probe: 4 lanes read one 64-B bucket (16 B each); round j serves the
-            // k-mers of lanes 16j..16j+15; lane 4g+j ends up owning k-mer 16j+g
-            uint4 ld[4];
-            uint32_t rkey[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int src = 16 * j + (int)(lane >> 2);
-                const uint32_t kb = __shfl(bucket, src, 64);
-                rkey[j] = __shfl(key, src, 64);
-                ld[j] = make_uint4(KH_EMPTY_KEY, 0, KH_EMPTY_KEY, 0);
-                if (rkey[j] != KH_EMPTY_KEY) ld[j] = p.table[(uint64_t)kb * 4 + (lane & 3u)];
-            }
-            uint32_t okey = KH_EMPTY_KEY, oval = 0, obucket = 0;
-            bool oempty = true;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t kk = rkey[j];
-                uint32_t r = (ld[j].x == kk) ? ld[j].y : ((ld[j].z == kk) ? ld[j].w : 0u);
-                uint32_t e = (ld[j].x == KH_EMPTY_KEY || ld[j].z == KH_EMPTY_KEY) ? 1u : 0u;
-                r |= __shfl_xor(r, 1, 64); e |= __shfl_xor(e, 1, 64);
-                r |= __shfl_xor(r, 2, 64); e |= __shfl_xor(e, 2, 64);
-                const int src = 16 * j + (int)(lane >> 2);
-                const uint32_t kb = __shfl(bucket, src, 64);
-                if ((lane & 3u) == (uint32_t)j) { okey = kk; oval = r; oempty = (e != 0u); obucket = kb; }
-            }
-            const bool valid = okey != KH_EMPTY_KEY;
-            const uint32_t opos = (uint32_t)c0 + 16u * (lane & 3u) + (lane >> 2);
-            if (valid) { c_lookup++; c_probe++; }
-            // rare: home bucket full and key not in it -> walk following buckets alone
-            if (valid && oval == 0u && !oempty) {
-                for (uint64_t tries = 1; tries < p.n_buckets; tries++) {
-                    obucket = (obucket + 1u == (uint32_t)p.n_buckets) ? 0u : obucket + 1u;
-                    c_probe++;
-                    bool e = false;
-#pragma unroll
-                    for (int s = 0; s < 4; s++) {
-                        const uint4 v = p.table[(uint64_t)obucket * 4 + s];
-                        if (v.x == okey) oval = v.y;
-                        if (v.z == okey) oval = v.w;
-                        e = e || v.x == KH_EMPTY_KEY || v.z == KH_EMPTY_KEY;
-                    }
-                    if (oval != 0u || e) break;
-                }
-            }
-            // ---- postings -> counting table
-            const bool found = valid && oval != 0u;
-            bool coop = false;
-            uint32_t lcnt = 0;
-            bool ok = true;
-            if (found) {
-                c_found++;
-                if (oval & KH_INLINE_BIT) {
-                    c_post++;
-                    ok = table_add<LOG2CAP>(t_keys, t_cnt, t_min, &s_nd, oval & ~KH_INLINE_BIT, opos);
-                } else {
-                    const uint4 *a = reinterpret_cast<const uint4 *>(p.arena) + oval;
-                    const uint4 w = a[0];
-                    lcnt = w.x;
-                    c_post += lcnt;
-                    c_lists++;
-                    c_lids += lcnt;
-                    if (lcnt > COOP_LIST_THRESHOLD) {
-                        coop = true;
-                    } else {
-                        ok = table_add<LOG2CAP>(t_keys, t_cnt, t_min, &s_nd, w.y, opos);
-                        if (ok && lcnt > 1) ok = table_add<LOG2CAP>(t_keys, t_cnt, t_min, &s_nd, w.z, opos);
-                        if (ok && lcnt > 2) ok = table_add<LOG2CAP>(t_keys, t_cnt, t_min, &s_nd, w.w, opos);
-                        for (uint32_t i = 3; ok && i < lcnt; i += 4) {
-                            const uint4 x = a[1 + (i - 3) / 4];
-                            ok = table_add<LOG2CAP>(t_keys, t_cnt, t_min, &s_nd, x.x, opos);
-                            if (ok && i + 1 < lcnt) ok = table_add<LOG2CAP>(t_keys, t_cnt, t_min, &s_nd, x.y, opos);
-                            if (ok && i + 2 < lcnt) ok = table_add<LOG2CAP>(t_keys, t_cnt, t_min, &s_nd, x.z, opos);
-                            if (ok && i + 3 < lcnt) ok = table_add<LOG2CAP>(t_keys, t_cnt, t_min, &s_nd, x.w, opos);
-                        }
-                    }
-                }
-            }
+        for (int32_t r0 = 0; r0 < size && !overflow; r0 += 64 * WAVES * NWIN) {
+            const bool ok = count_windows<LdsTable<LOG2CAP>, NWIN, false>(p, vals, heads, size, r0 + 64 * (int32_t)wv,
+                                                                         64 * WAVES, tab, pc, s_pref[wv]);
             if (!ok) s_ovf = 1;
-            // long lists: the whole wave walks them, coalesced
-            unsigned long long m = __ballot(coop);
-            while (m) {
-                const int src = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                const uint32_t off = __shfl(oval, src, 64);
-                const uint32_t n = __shfl(lcnt, src, 64);
-                const uint32_t pos = __shfl(opos, src, 64);
-                const uint32_t *ids = p.arena + (uint64_t)off * 4 + 1;
-                bool ok2 = true;
-                for (uint32_t i = lane; ok2 && i < n; i += 64) ok2 = table_add<LOG2CAP>(t_keys, t_cnt, t_min, &s_nd, ids[i], pos);
-                if (!ok2) s_ovf = 1;
-                if (*(volatile uint32_t *)&s_nd > CAP_LIMIT) break;
-            }
             __syncthreads();
-            overflow = (*(volatile uint32_t *)&s_ovf != 0u) || (*(volatile uint32_t *)&s_nd > CAP_LIMIT);
+            overflow = (*(volatile uint32_t *)&s_ovf != 0u) || tab.over_limit();
+            if (WAVES > 1) __syncthreads();
         }
 
         if (overflow) {
-            // hand the query to the global-memory tier
-            if (lane == 0) {
-                c_ovf++;
-                uint32_t slot = atomicAdd(p.ovf_count, 1u);
-                if (slot < p.ovf_cap) p.ovf_list[slot] = q;
-                else atomicOr(p.status, (uint32_t)ST_OVF_LIST_FULL);
+            // hand the query to the next tier; its postings are counted there
+            if (wv == 0) tot_ovf++;
+            if (tid == 0) {
+                const uint32_t slot = atomicAdd(p.ovf_count, 1u);
+                if (slot < p.list_cap) p.ovf_list[slot] = wi;
+                else atomicOr(p.status, (uint32_t)ST_LIST_FULL);
                 p.q_cnt[q] = 0;
                 p.q_start[q] = 0;
             }
+        } else {
+            tot_post += wave_total(pc.post); tot_lists += wave_total(pc.lists); tot_lids += wave_total(pc.lids);
+            if (wv == 0) { tot_q++; tot_in += (unsigned long long)size + 6; }
+            // ---- compaction: ballot + prefix popcount -> dense hit list in the pool
+            const uint32_t total = (p.ablate & 16u) ? 0u : *(volatile uint32_t *)&s_nd;
+            uint64_t base = 0;
+            bool have = true;
+            if (total > 0) {
+                if (WAVES == 1) {
+                    if (total > chunk_left) {
+                        const uint32_t need = total > POOL_CHUNK ? total : POOL_CHUNK;
+                        const uint32_t shard = blockIdx.x % POOL_SHARDS;
+                        unsigned long long b = 0;
+                        if (lane == 0) b = atomicAdd(&p.pool_cursor[shard * CURSOR_STRIDE], (unsigned long long)need);
+                        b = __shfl(b, 0, 64);
+                        if (b + need > p.pool_shard_cap) {
+                            if (lane == 0) atomicOr(p.status, (uint32_t)ST_POOL_FULL);
+                            have = false;
+                        } else {
+                            chunk_base = (uint64_t)shard * p.pool_shard_cap + b;
+                            chunk_left = need;
+                        }
+                    }
+                    if (have) {
+                        base = chunk_base;
+                        chunk_base += total;
+                        chunk_left -= total;
+                        uint32_t running = 0;
+                        for (uint32_t i0 = 0; i0 < (uint32_t)CAP; i0 += 64) {
+                            const uint32_t k = t_keys[i0 + lane];
+                            const bool has = k != KH_EMPTY_PID;
+                            const unsigned long long bm = __ballot(has);
+                            if (has && !(p.ablate & 4u)) {
+                                const uint32_t idx = running + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull));
+                                p.pool_pid[base + idx] = k;
+                                p.pool_km[base + idx] = t_cnt[i0 + lane];
+                                p.pool_fp[base + idx] = t_min[i0 + lane];
+                            }
+                            running += (uint32_t)__popcll(bm);
+                        }
+                    }
+                } else {
+                    if (tid == 0) {
+                        const uint32_t shard = blockIdx.x % POOL_SHARDS;
+                        const unsigned long long b = atomicAdd(&p.pool_cursor[shard * CURSOR_STRIDE], (unsigned long long)total);
+                        if (b + total > p.pool_shard_cap) { atomicOr(p.status, (uint32_t)ST_POOL_FULL); s_base = ~0ull; }
+                        else s_base = (unsigned long long)shard * p.pool_shard_cap + b;
+                    }
+                    for (uint32_t st = wv; st < (uint32_t)STRIPES; st += WAVES) {
+                        const unsigned long long bm = __ballot(t_keys[st * 64 + lane] != KH_EMPTY_PID);
+                        if (lane == 0) s_stripe[st] = (uint32_t)__popcll(bm);
+                    }
+                    __syncthreads();
+                    base = s_base;
+                    have = base != ~0ull;
+                    if (have) {
+                        for (uint32_t st = wv; st < (uint32_t)STRIPES; st += WAVES) {
+                            const uint32_t before = wave_sum32(lane < st ? s_stripe[lane] : 0u);
+                            const uint32_t k = t_keys[st * 64 + lane];
+                            const bool has = k != KH_EMPTY_PID;
+                            const unsigned long long bm = __ballot(has);
+                            if (has) {
+                                const uint32_t idx = before + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull));
+                                p.pool_pid[base + idx] = k;
+                                p.pool_km[base + idx] = t_cnt[st * 64 + lane];
+                                p.pool_fp[base + idx] = t_min[st * 64 + lane];
+                            }
+                        }
+                    }
+                }
+                if (wv == 0 && have) tot_hits += total;
+            }
+            if (tid == 0) { p.q_cnt[q] = have ? total : 0u; p.q_start[q] = have ? base : 0; }
+        }
+        // static striding: one shared queue word would serialise every wave of the grid
+        // behind the L2 atomic unit (~88 dequeues/us)
+        item += gridDim.x;
+        __syncthreads();
+    }
+    if (lane == 0) {
+        const uint32_t rep = blockIdx.x * WAVES + wv;
+        add_counter(p.counters, rep, CTR_IN, tot_in);
+        add_counter(p.counters, rep, CTR_QUERIES, tot_q);
+        add_counter(p.counters, rep, CTR_POST, tot_post);
+        add_counter(p.counters, rep, CTR_HITS, tot_hits);
+        add_counter(p.counters, rep, CTR_OVERFLOW, tot_ovf);
+        add_counter(p.counters, rep, CTR_LISTS, tot_lists);
+        add_counter(p.counters, rep, CTR_LIST_IDS, tot_lids);
+    }
+}
+
+// ---- G tier: counting table in HBM, sized from the query's exact postings count -------------------
+struct NullTable {
+    uint32_t *nd;
+    __device__ __forceinline__ bool add_n(uint32_t, uint32_t, uint32_t, uint32_t &) const { return true; }
+    __device__ __forceinline__ bool over_limit() const { return false; }
+};
+
+__global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams p)
+{
+    constexpr int WAVES = G_WAVES;
+    __shared__ uint32_t s_nd, s_fail, s_cursor;
+    constexpr int NWIN = 2;
+    __shared__ uint32_t s_pref[WAVES][NWIN * 64];
+    __shared__ unsigned long long s_post, s_off, s_base;
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    const uint32_t n_items = *p.list_count < p.list_cap ? *p.list_count : p.list_cap;
+    unsigned long long tot_in = 0, tot_q = 0, tot_post = 0, tot_hits = 0, tot_lists = 0, tot_lids = 0;
+    PostCtr pc;
+    NullTable nt;
+    nt.nd = &s_nd;
+
+    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const WorkItem wi = p.list[item];
+        const uint32_t q = wi.q;
+        const int32_t size = wi.size;
+        const uint32_t *vals = p.vals + wi.aa_off;
+        const uint4 *heads = p.heads + wi.aa_off;
+        if (tid == 0) { s_nd = 0; s_fail = 0; s_post = 0; s_cursor = 0; }
+        __syncthreads();
+        // pass 1: exact number of postings (an upper bound of the distinct proteins)
+        pc.clear();
+        for (int32_t r0 = 0; r0 < size; r0 += 64 * WAVES * NWIN)
+            count_windows<NullTable, NWIN, true>(p, vals, heads, size, r0 + 64 * (int32_t)wv, 64 * WAVES, nt, pc, s_pref[wv]);
+        {
+            const unsigned long long wp = wave_total(pc.post);
+            if (lane == 0 && wp) atomicAdd(&s_post, wp);
+        }
+        __syncthreads();
+        unsigned long long bound = s_post;
+        if (bound > p.n_proteins) bound = p.n_proteins;
+        uint32_t log2cap = 10;
+        while ((1ull << log2cap) < 2 * bound && log2cap < 31) log2cap++;
+        const unsigned long long cap = 1ull << log2cap;
+        if (tid == 0) {
+            const unsigned long long off = atomicAdd(p.g_cursor, cap);
+            if (off + cap > p.g_slots) { atomicOr(p.status, (uint32_t)ST_G_ARENA_FULL); s_off = ~0ull; }
+            else s_off = off;
+        }
+        __syncthreads();
+        const unsigned long long off = s_off;
+        if (off == ~0ull) {
+            if (tid == 0) { p.q_cnt[q] = 0; p.q_start[q] = 0; }
             __syncthreads();
             continue;
         }
-
-        // ---- compaction: ballot + prefix popcount -> dense hit list in the pool
-        const uint32_t total = *(volatile uint32_t *)&s_nd;
-        uint64_t base = 0;
-        bool have = true;
-        if (total > 0) {
-            if (total > chunk_left) {
-                const uint32_t need = total > POOL_CHUNK ? total : POOL_CHUNK;
-                unsigned long long b = 0;
-                if (lane == 0) b = atomicAdd(p.pool_cursor, (unsigned long long)need);
-                b = __shfl(b, 0, 64);
-                if (b + need > p.pool_cap) {
-                    if (lane == 0) atomicOr(p.status, (uint32_t)ST_POOL_FULL);
-                    have = false;
-                } else {
-                    chunk_base = b;
-                    chunk_left = need;
-                }
-            }
-            if (have) {
-                base = chunk_base;
-                chunk_base += total;
-                chunk_left -= total;
-                uint32_t running = 0;
-                for (uint32_t i0 = 0; i0 < (uint32_t)CAP; i0 += 64) {
-                    const uint32_t k = t_keys[i0 + lane];
-                    const bool has = k != KH_EMPTY_PID;
-                    const unsigned long long bm = __ballot(has);
-                    if (has) {
-                        const uint32_t idx = running + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull));
-                        p.pool_pid[base + idx] = k;
-                        p.pool_km[base + idx] = t_cnt[i0 + lane];
-                        p.pool_fp[base + idx] = t_min[i0 + lane];
-                    }
-                    running += (uint32_t)__popcll(bm);
-                }
-                if (lane == 0) c_hits += total;
+        GlobalTable gt;
+        gt.keys = p.g_keys + off; gt.cnt = p.g_cnt + off; gt.minpos = p.g_min + off; gt.nd = &s_nd; gt.log2cap = log2cap;
+        for (unsigned long long i = tid; i < cap; i += 64 * WAVES) { gt.keys[i] = KH_EMPTY_PID; gt.cnt[i] = 0; gt.minpos[i] = 0xFFFFFFFFu; }
+        __threadfence();
+        __syncthreads();
+        // pass 2: count
+        pc.clear();
+        for (int32_t r0 = 0; r0 < size; r0 += 64 * WAVES * NWIN) {
+            const bool ok = count_windows<GlobalTable, NWIN, false>(p, vals, heads, size, r0 + 64 * (int32_t)wv, 64 * WAVES, gt,
+                                                                   pc, s_pref[wv]);
+            if (!ok) s_fail = 1;
+        }
+        __threadfence();
+        __syncthreads();
+        tot_post += wave_total(pc.post); tot_lists += wave_total(pc.lists); tot_lids += wave_total(pc.lids);
+        if (wv == 0) { tot_q++; tot_in += (unsigned long long)size + 6; }
+        const uint32_t total = s_nd;
+        const bool failed = s_fail != 0;
+        if (tid == 0) {
+            if (failed) { atomicOr(p.status, (uint32_t)ST_G_TABLE_FULL); s_base = ~0ull; }
+            else if (total == 0) s_base = 0;
+            else {
+                const uint32_t shard = blockIdx.x % POOL_SHARDS;
+                const unsigned long long b = atomicAdd(&p.pool_cursor[shard * CURSOR_STRIDE], (unsigned long long)total);
+                if (b + total > p.pool_shard_cap) { atomicOr(p.status, (uint32_t)ST_POOL_FULL); s_base = ~0ull; }
+                else s_base = (unsigned long long)shard * p.pool_shard_cap + b;
             }
         }
-        if (lane == 0) { p.q_cnt[q] = have ? total : 0u; p.q_start[q] = base; }
+        __syncthreads();
+        const unsigned long long base = s_base;
+        if (base != ~0ull && total > 0) {
+            for (unsigned long long i0 = (unsigned long long)wv * 64; i0 < cap; i0 += 64 * WAVES) {
+                const uint32_t k = __hip_atomic_load(&gt.keys[i0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool has = k != KH_EMPTY_PID;
+                const unsigned long long bm = __ballot(has);
+                uint32_t wbase = 0;
+                if (lane == 0 && bm) wbase = atomicAdd(&s_cursor, (uint32_t)__popcll(bm));
+                wbase = __shfl(wbase, 0, 64);
+                if (has) {
+                    const uint32_t idx = wbase + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull));
+                    p.pool_pid[base + idx] = k;
+                    p.pool_km[base + idx] = __hip_atomic_load(&gt.cnt[i0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    p.pool_fp[base + idx] = __hip_atomic_load(&gt.minpos[i0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (wv == 0) tot_hits += total;
+        }
+        if (tid == 0) { p.q_cnt[q] = (base != ~0ull) ? total : 0u; p.q_start[q] = base == ~0ull ? 0 : base; }
         __syncthreads();
     }
-
-    // ---- counters: one replica line per 64 waves
-    c_lookup = wave_sum(c_lookup); c_probe = wave_sum(c_probe);
-    c_found = wave_sum(c_found);   c_post = wave_sum(c_post);
-    c_lists = wave_sum(c_lists);   c_lids = wave_sum(c_lids);
     if (lane == 0) {
-        unsigned long long *c = p.counters + (size_t)(wave % CTR_REPLICAS) * CTR_N;
-        if (c_in) atomicAdd(&c[CTR_IN], c_in);
-        if (c_q) atomicAdd(&c[CTR_QUERIES], c_q);
-        if (c_lookup) atomicAdd(&c[CTR_LOOKUP], c_lookup);
-        if (c_probe) atomicAdd(&c[CTR_PROBE], c_probe);
-        if (c_found) atomicAdd(&c[CTR_FOUND], c_found);
-        if (c_post) atomicAdd(&c[CTR_POST], c_post);
-        if (c_hits) atomicAdd(&c[CTR_HITS], c_hits);
-        if (c_ovf) atomicAdd(&c[CTR_OVERFLOW], c_ovf);
-        if (c_lists) atomicAdd(&c[CTR_LISTS], c_lists);
-        if (c_lids) atomicAdd(&c[CTR_LIST_IDS], c_lids);
+        const uint32_t rep = blockIdx.x * WAVES + wv;
+        add_counter(p.counters, rep, CTR_IN, tot_in);
+        add_counter(p.counters, rep, CTR_QUERIES, tot_q);
+        add_counter(p.counters, rep, CTR_POST, tot_post);
+        add_counter(p.counters, rep, CTR_HITS, tot_hits);
+        add_counter(p.counters, rep, CTR_LISTS, tot_lists);
+        add_counter(p.counters, rep, CTR_LIST_IDS, tot_lids);
     }
 }
 
 // ------------------------------------------------------------------------------------
-// prep: protein records -> query meta (search.go:286-296; search_protein.go:70-76)
+// prep: protein records -> query meta (search.go:286-296; search_protein.go:70-76),
+// the not-a-k-mer-start bitmap (all zero on entry) and the tier work lists.
 // ------------------------------------------------------------------------------------
-__global__ void prep_protein_kernel(const uint8_t *seqs, const uint64_t *offsets, uint32_t n_seqs,
-                                    kaamer_query_meta *q, uint32_t *d_nq)
+__device__ __forceinline__ void mark_invalid_range(unsigned long long *invalid, uint64_t b, uint64_t e)
+{
+    // sets bits [b, e)
+    while (b < e) {
+        const uint64_t w = b >> 6;
+        const uint64_t hi = ((w + 1) << 6) < e ? ((w + 1) << 6) : e;
+        const unsigned nb = (unsigned)(hi - b);
+        const unsigned long long m = (nb == 64 ? ~0ull : ((1ull << nb) - 1ull)) << (b & 63);
+        atomicOr(&invalid[w], m);
+        b = hi;
+    }
+}
+
+__global__ void prep_protein_kernel(const uint8_t *seqs, const uint64_t *offsets, uint32_t n_seqs, int32_t s_max_size,
+                                    kaamer_query_meta *q, uint32_t *d_nq, unsigned long long *d_n_pos,
+                                    unsigned long long *invalid, WorkItem *lists, uint32_t *list_counts,
+                                    uint32_t list_cap, uint64_t *q_start, uint32_t *q_cnt)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) *d_nq = n_seqs;
-    if (i >= n_seqs) return;
-    const uint64_t b = offsets[i], e = offsets[i + 1];
-    const int64_t len = (int64_t)(e - b);
-    int32_t size = (int32_t)(len - KAAMER_KMER_SIZE + 1);       // search.go:290
-    if (len > 0 && seqs[e - 1] == '*') size--;                  // search.go:291-293
-    kaamer_query_meta m;
-    m.src_seq = i;
-    m.size_in_kmer = size;
-    m.start_position = 1;                                       // search.go:225,303
-    m.end_position = (int32_t)len;                              // search.go:294
-    m.plus_strand = 1;
-    m.aa_len = (uint32_t)len;
-    m.aa_off = b;
-    m.sa_off = 0;
-    m.sa_len = 0;
-    q[i] = m;
+    if (i == 0) {
+        const uint64_t n_pos = offsets[n_seqs];
+        *d_nq = n_seqs;
+        *d_n_pos = n_pos;
+        mark_invalid_range(invalid, n_pos, (n_pos + 63) & ~63ull);  // bits past the end, in the last word P reads
+    }
+    int which = -1;
+    WorkItem wi;
+    wi.q = i; wi.size = 0; wi.aa_off = 0;
+    if (i < n_seqs) {
+        const uint64_t b = offsets[i], e = offsets[i + 1];
+        const int64_t len = (int64_t)(e - b);
+        int32_t size = (int32_t)(len - KAAMER_KMER_SIZE + 1);       // search.go:290
+        if (len > 0 && seqs[e - 1] == '*') size--;                  // search.go:291-293
+        kaamer_query_meta m;
+        m.src_seq = i;
+        m.size_in_kmer = size;
+        m.start_position = 1;                                       // search.go:225,303
+        m.end_position = (int32_t)len;                              // search.go:294
+        m.plus_strand = 1;
+        m.aa_len = (uint32_t)len;
+        m.aa_off = b;
+        m.sa_off = 0;
+        m.sa_len = 0;
+        q[i] = m;
+        q_cnt[i] = 0;
+        q_start[i] = 0;
+        wi.size = size;
+        wi.aa_off = b;
+        if (size >= 7) {                                            // search_protein.go:74-76
+            which = size <= s_max_size ? LIST_S : LIST_L;
+            mark_invalid_range(invalid, b + (uint64_t)size, e);      // positions >= SizeInKmer start no k-mer
+        } else {
+            mark_invalid_range(invalid, b, e);                       // the whole query is dropped
+        }
+    }
+    // wave-aggregated append to the tier lists
+#pragma unroll
+    for (int l = LIST_S; l <= LIST_L; l++) {
+        const unsigned long long m = __ballot(which == l);
+        if (m) {
+            uint32_t base = 0;
+            const uint32_t lane = threadIdx.x & 63u;
+            if (lane == (uint32_t)(__ffsll((long long)m) - 1)) base = atomicAdd(&list_counts[l], (uint32_t)__popcll(m));
+            base = __shfl(base, __ffsll((long long)m) - 1, 64);
+            if (which == l) lists[(size_t)l * list_cap + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = wi;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------
-// exclusive scan of q_cnt[0..nq) -> hit_off[0..nq], three launches
+// exclusive scan of q_cnt[0..nq) -> hit_off[0..nq]
 // ------------------------------------------------------------------------------------
-#define SCAN_BLOCK 256
-#define SCAN_ITEMS 8
+#define SCAN_BLOCK 1024
+#define SCAN_ITEMS 16
 #define SCAN_TILE (SCAN_BLOCK * SCAN_ITEMS)
 
 __device__ __forceinline__ uint64_t block_exclusive_scan(uint64_t v, uint64_t *total)
@@ -398,6 +846,33 @@ __device__ __forceinline__ uint64_t block_exclusive_scan(uint64_t v, uint64_t *t
     }
     *total = tot;
     return woff + inc - v;
+}
+
+// one block walks all tiles with a carry: one launch, for batches of up to ~1e5 queries
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_single_kernel(const uint32_t *cnt, const uint32_t *d_nq, uint64_t *hit_off)
+{
+    const uint32_t nq = *d_nq;
+    uint64_t carry = 0;
+    for (uint64_t base = 0; base <= nq; base += SCAN_TILE) {
+        uint32_t v[SCAN_ITEMS];
+        uint64_t s = 0;
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; i++) {
+            const uint64_t idx = base + (uint64_t)threadIdx.x * SCAN_ITEMS + i;
+            v[i] = idx < nq ? cnt[idx] : 0u;
+            s += v[i];
+        }
+        uint64_t tot;
+        uint64_t ex = block_exclusive_scan(s, &tot) + carry;
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; i++) {
+            const uint64_t idx = base + (uint64_t)threadIdx.x * SCAN_ITEMS + i;
+            if (idx <= nq) hit_off[idx] = ex;
+            ex += v[i];
+        }
+        carry += tot;
+        __syncthreads();
+    }
 }
 
 __global__ __launch_bounds__(SCAN_BLOCK) void scan_block_sums_kernel(const uint32_t *cnt, const uint32_t *d_nq,
@@ -455,37 +930,48 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_apply_kernel(const uint32_t *
     }
 }
 
-// pool -> CSR: one thread per output hit, owner query found by binary search
-__global__ void gather_hits_kernel(const uint32_t *d_nq, const uint64_t *hit_off, const uint64_t *q_start,
-                                   const uint32_t *pool_pid, const uint32_t *pool_km, const uint32_t *pool_fp,
-                                   uint32_t *out_pid, uint32_t *out_km, uint32_t *out_fp, uint64_t out_cap,
-                                   uint32_t *status)
+// pool -> CSR in query order: one wave per query copies its hit list
+__global__ __launch_bounds__(256) void gather_hits_kernel(const uint32_t *d_nq, const uint64_t *hit_off,
+                                                          const uint64_t *q_start, const uint32_t *q_cnt,
+                                                          const uint32_t *pool_pid, const uint32_t *pool_km,
+                                                          const uint32_t *pool_fp, uint32_t *out_pid, uint32_t *out_km,
+                                                          uint32_t *out_fp, uint64_t out_cap, uint32_t *status)
 {
     const uint32_t nq = *d_nq;
     const uint64_t n_hits = hit_off[nq];
     if (n_hits > out_cap) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(status, (uint32_t)ST_POOL_FULL); return; }
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_hits; i += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t lo = 0, hi = nq;  // last q with hit_off[q] <= i
-        while (hi - lo > 1) {
-            const uint32_t mid = lo + (hi - lo) / 2;
-            if (hit_off[mid] <= i) lo = mid; else hi = mid;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t q = wave; q < nq; q += n_waves) {
+        const uint32_t n = q_cnt[q];
+        if (n == 0) continue;
+        const uint64_t s = q_start[q], d = hit_off[q];
+        for (uint32_t i = lane; i < n; i += 64) {
+            out_pid[d + i] = pool_pid[s + i];
+            out_km[d + i] = pool_km[s + i];
+            out_fp[d + i] = pool_fp[s + i];
         }
-        const uint64_t src = q_start[lo] + (i - hit_off[lo]);
-        out_pid[i] = pool_pid[src];
-        out_km[i] = pool_km[src];
-        out_fp[i] = pool_fp[src];
     }
 }
 
-__global__ void finalize_counters_kernel(const unsigned long long *replicas, kaamer_counters *out,
-                                         const uint32_t *ovf_count, uint32_t *status)
+// Sums the counter replicas, publishes status, and leaves every piece of per-batch device
+// state zeroed for the next batch (no memsets in the steady state).
+__global__ void finalize_kernel(unsigned long long *replicas, kaamer_counters *out, uint32_t *small_state,
+                                uint32_t *status_out, unsigned long long *cursors)
 {
     if (threadIdx.x < CTR_N) {
         unsigned long long s = 0;
-        for (int r = 0; r < CTR_REPLICAS; r++) s += replicas[(size_t)r * CTR_N + threadIdx.x];
+        for (int r = 0; r < CTR_REPLICAS; r++) {
+            s += replicas[(size_t)r * CTR_N + threadIdx.x];
+            replicas[(size_t)r * CTR_N + threadIdx.x] = 0;
+        }
         ((unsigned long long *)out)[threadIdx.x] = s;
     }
-    if (threadIdx.x == 0 && *ovf_count != 0) atomicOr(status, (uint32_t)ST_OVERFLOW_UNSERVED);
+    if (threadIdx.x == 0) *status_out = small_state[N_LISTS + 1];
+    __syncthreads();
+    if (threadIdx.x < N_LISTS + 2) small_state[threadIdx.x] = 0;
+    for (uint32_t i = threadIdx.x; i <= POOL_SHARDS; i += blockDim.x) cursors[i * CURSOR_STRIDE] = 0;  // + the G arena cursor
 }
 
 // ------------------------------------------------------------------------------------
@@ -495,29 +981,40 @@ struct kaamer_workspace {
     int device;
     kaamer_workspace_opts opts;
     uint32_t q_cap;
-    uint64_t hit_cap, pool_cap;
-    uint32_t lds_log2;
-    int search_grid;
+    uint64_t hit_cap, pool_cap, g_slots, pos_cap;
+    uint32_t s_log2;
+    int32_t s_max_size;
+    int s_grid, l_grid, g_grid, p_grid, n_cu;
     // device buffers
     kaamer_query_meta *d_q;
     uint32_t *d_nq;
+    unsigned long long *d_n_pos;
+    unsigned long long *d_valid;        // one bit per residue position
+    uint32_t *d_vals;                   // probe result per residue position
     uint64_t *d_q_start;
     uint32_t *d_q_cnt;
     uint32_t *d_pool_pid, *d_pool_km, *d_pool_fp;
-    unsigned long long *d_pool_cursor;
-    uint32_t *d_ovf_list, *d_ovf_count;
-    uint32_t ovf_cap;
+    unsigned long long *d_pool_cursor;  // POOL_SHARDS pool cursors + the G arena cursor, CURSOR_STRIDE apart
+    WorkItem *d_lists;                  // [N_LISTS][q_cap]
+    uint4 *d_heads;                     // postings heads per residue position
+    hipStream_t side;                   // the L tier runs beside the S tier
+    hipEvent_t ev_fork, ev_join;
+    uint32_t *d_list_counts;            // [N_LISTS] + queue head + status (zeroed by finalize)
+    uint32_t *d_status_out;             // status of the last finished batch
+    bool clean;                         // per-batch device state is known to be zeroed
+    uint32_t *d_g_keys, *d_g_cnt, *d_g_min;
     unsigned long long *d_counter_replicas;
     kaamer_counters *d_counters;
-    uint32_t *d_status;
     uint64_t *d_bsum;
     uint32_t n_scan_blocks;
     uint64_t *d_hit_off;
     uint32_t *d_hit_pid, *d_hit_km, *d_hit_fp;
-    std::vector<hipEvent_t> *ev;  // 4 events per timed call: total0, search0, search1, total1
+    std::vector<hipEvent_t> *ev;  // 5 events per timed call: total0, probe0, probe1(=count0), count1, total1
     uint32_t n_timed;
     bool timed;
 };
+enum { SLOT_QUEUE_HEAD = N_LISTS, SLOT_STATUS = N_LISTS + 1, N_SMALL_SLOTS = N_LISTS + 2 };
+#define EV_PER_CALL 5
 
 template <class T> static int dev_alloc(T **p, size_t n)
 {
@@ -527,14 +1024,13 @@ template <class T> static int dev_alloc(T **p, size_t n)
     return KAAMER_OK;
 }
 
-template <int L> static void launch_search(const SearchParams &p, int grid, hipStream_t s)
+template <int L> static void launch_s(const CountParams &p, int grid, hipStream_t s)
 {
-    hipLaunchKernelGGL(kmer_search_kernel<L>, dim3(grid), dim3(64), 0, s, p);
+    hipLaunchKernelGGL((count_lds_kernel<L, 1>), dim3(grid), dim3(64), 0, s, p);
 }
-
-template <int L> static int search_occupancy(int *blocks_per_cu)
+template <int L> static int s_occupancy(int *blocks_per_cu)
 {
-    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, kmer_search_kernel<L>, 64, 0));
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, count_lds_kernel<L, 1>, 64, 0));
     return KAAMER_OK;
 }
 
@@ -594,14 +1090,18 @@ void kaamer_workspace_free(kaamer_workspace *ws)
 {
     if (!ws) return;
     (void)hipSetDevice(ws->device);
-    void *bufs[] = { ws->d_q, ws->d_nq, ws->d_q_start, ws->d_q_cnt, ws->d_pool_pid, ws->d_pool_km, ws->d_pool_fp,
-                     ws->d_pool_cursor, ws->d_ovf_list, ws->d_ovf_count, ws->d_counter_replicas, ws->d_counters,
-                     ws->d_status, ws->d_bsum, ws->d_hit_off, ws->d_hit_pid, ws->d_hit_km, ws->d_hit_fp };
+    void *bufs[] = { ws->d_q, ws->d_nq, ws->d_n_pos, ws->d_valid, ws->d_vals, ws->d_heads, ws->d_q_start, ws->d_q_cnt, ws->d_pool_pid,
+                     ws->d_pool_km, ws->d_pool_fp, ws->d_pool_cursor, ws->d_lists, ws->d_list_counts, ws->d_status_out, ws->d_g_keys,
+                     ws->d_g_cnt, ws->d_g_min, ws->d_counter_replicas, ws->d_counters, ws->d_bsum, ws->d_hit_off,
+                     ws->d_hit_pid, ws->d_hit_km, ws->d_hit_fp };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (ws->ev) {
         for (hipEvent_t e : *ws->ev) (void)hipEventDestroy(e);
         delete ws->ev;
     }
+    if (ws->ev_fork) (void)hipEventDestroy(ws->ev_fork);
+    if (ws->ev_join) (void)hipEventDestroy(ws->ev_join);
+    if (ws->side) (void)hipStreamDestroy(ws->side);
     delete ws;
 }
 
@@ -617,46 +1117,65 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     ws->opts = *opts;
     ws->q_cap = opts->max_queries ? opts->max_queries : opts->max_seqs;
     if (ws->q_cap < 1) ws->q_cap = 1;
-    ws->hit_cap = opts->max_hits ? opts->max_hits : (uint64_t)ws->q_cap * 64 + (1u << 20);
-    uint32_t slots = opts->lds_slots ? opts->lds_slots : 512;
+    ws->pos_cap = opts->max_seq_bytes + 64;
+    ws->hit_cap = opts->max_hits ? opts->max_hits : (uint64_t)ws->q_cap * 256 + (1u << 20);
+    const uint32_t slots = opts->lds_slots ? opts->lds_slots : 512;
     uint32_t l2 = 6;
-    while ((1u << l2) < slots && l2 < 12) l2++;
-    if ((1u << l2) != slots) { delete ws; return kaamer_fail(KAAMER_E_ARG, "lds_slots must be a power of two in [64,4096]"); }
-    ws->lds_log2 = l2;
-    int per_cu = 0, rc = KAAMER_OK;
+    while ((1u << l2) < slots && l2 < 11) l2++;
+    if ((1u << l2) != slots) { delete ws; return kaamer_fail(KAAMER_E_ARG, "lds_slots must be a power of two in [64,2048]"); }
+    ws->s_log2 = l2;
+    ws->s_max_size = opts->s_tier_max_kmers ? (int32_t)opts->s_tier_max_kmers : 384;
+    if (const char *e = getenv("KAAMER_S_MAX_KMERS")) ws->s_max_size = atoi(e);
+    ws->g_slots = opts->g_tier_slots ? opts->g_tier_slots : (32ull << 20);
+    int per_cu = 0, l_per_cu = 0, p_per_cu = 0, rc = KAAMER_OK;
     switch (l2) {
-    case 6: rc = search_occupancy<6>(&per_cu); break;
-    case 7: rc = search_occupancy<7>(&per_cu); break;
-    case 8: rc = search_occupancy<8>(&per_cu); break;
-    case 9: rc = search_occupancy<9>(&per_cu); break;
-    case 10: rc = search_occupancy<10>(&per_cu); break;
-    case 11: rc = search_occupancy<11>(&per_cu); break;
-    default: rc = search_occupancy<12>(&per_cu); break;
+    case 6: rc = s_occupancy<6>(&per_cu); break;
+    case 7: rc = s_occupancy<7>(&per_cu); break;
+    case 8: rc = s_occupancy<8>(&per_cu); break;
+    case 9: rc = s_occupancy<9>(&per_cu); break;
+    case 10: rc = s_occupancy<10>(&per_cu); break;
+    default: rc = s_occupancy<11>(&per_cu); break;
     }
     if (rc) { delete ws; return rc; }
+    hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&l_per_cu, count_lds_kernel<L_LOG2CAP, L_WAVES>, 64 * L_WAVES, 0);
+    if (oe == hipSuccess) oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&p_per_cu, probe_kernel, 64 * P_WAVES, 0);
+    if (oe != hipSuccess) { delete ws; return kaamer_fail(KAAMER_E_HIP, "occupancy query: %s", hipGetErrorString(oe)); }
     hipDeviceProp_t prop;
     hipError_t pe = hipGetDeviceProperties(&prop, ix->device);
     if (pe != hipSuccess) { delete ws; return kaamer_fail(KAAMER_E_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(pe)); }
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 32) per_cu = 32;
-    ws->search_grid = prop.multiProcessorCount * per_cu;
-    // every resident wave may hold one partly used chunk
-    ws->pool_cap = ws->hit_cap + (uint64_t)ws->search_grid * POOL_CHUNK;
-    ws->ovf_cap = ws->q_cap;
+    if (l_per_cu < 1) l_per_cu = 1;
+    if (p_per_cu < 1) p_per_cu = 1;
+    ws->n_cu = prop.multiProcessorCount;
+    ws->s_grid = ws->n_cu * per_cu;
+    ws->l_grid = ws->n_cu * l_per_cu;
+    ws->g_grid = ws->n_cu * 2;
+    ws->p_grid = ws->n_cu * p_per_cu;
+    // every resident S wave may hold one partly used chunk; shards fill unevenly (+25 %)
+    ws->pool_cap = ws->hit_cap + ws->hit_cap / 4 + (uint64_t)ws->s_grid * POOL_CHUNK + POOL_SHARDS * 4096ull;
+    ws->pool_cap = (ws->pool_cap + POOL_SHARDS - 1) / POOL_SHARDS * POOL_SHARDS;
     ws->n_scan_blocks = (uint32_t)(((uint64_t)ws->q_cap + 1 + SCAN_TILE - 1) / SCAN_TILE);
     rc = dev_alloc(&ws->d_q, ws->q_cap);
     if (!rc) rc = dev_alloc(&ws->d_nq, 1);
+    if (!rc) rc = dev_alloc(&ws->d_n_pos, 1);
+    if (!rc) rc = dev_alloc(&ws->d_valid, (size_t)(ws->pos_cap / 64 + 2));
+    if (!rc) rc = dev_alloc(&ws->d_vals, (size_t)ws->pos_cap);
+    if (!rc) rc = dev_alloc(&ws->d_heads, (size_t)ws->pos_cap);
     if (!rc) rc = dev_alloc(&ws->d_q_start, ws->q_cap);
     if (!rc) rc = dev_alloc(&ws->d_q_cnt, ws->q_cap);
     if (!rc) rc = dev_alloc(&ws->d_pool_pid, ws->pool_cap);
     if (!rc) rc = dev_alloc(&ws->d_pool_km, ws->pool_cap);
     if (!rc) rc = dev_alloc(&ws->d_pool_fp, ws->pool_cap);
-    if (!rc) rc = dev_alloc(&ws->d_pool_cursor, 1);
-    if (!rc) rc = dev_alloc(&ws->d_ovf_list, ws->ovf_cap);
-    if (!rc) rc = dev_alloc(&ws->d_ovf_count, 1);
+    if (!rc) rc = dev_alloc(&ws->d_pool_cursor, (size_t)(POOL_SHARDS + 1) * CURSOR_STRIDE);
+    if (!rc) rc = dev_alloc(&ws->d_lists, (size_t)N_LISTS * ws->q_cap);
+    if (!rc) rc = dev_alloc(&ws->d_list_counts, N_SMALL_SLOTS);
+    if (!rc) rc = dev_alloc(&ws->d_status_out, 1);
+    if (!rc) rc = dev_alloc(&ws->d_g_keys, ws->g_slots);
+    if (!rc) rc = dev_alloc(&ws->d_g_cnt, ws->g_slots);
+    if (!rc) rc = dev_alloc(&ws->d_g_min, ws->g_slots);
     if (!rc) rc = dev_alloc(&ws->d_counter_replicas, (size_t)CTR_REPLICAS * CTR_N);
     if (!rc) rc = dev_alloc(&ws->d_counters, 1);
-    if (!rc) rc = dev_alloc(&ws->d_status, 1);
     if (!rc) rc = dev_alloc(&ws->d_bsum, ws->n_scan_blocks);
     if (!rc) rc = dev_alloc(&ws->d_hit_off, (size_t)ws->q_cap + 1);
     if (!rc) rc = dev_alloc(&ws->d_hit_pid, ws->hit_cap);
@@ -665,6 +1184,12 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     if (rc) { kaamer_workspace_free(ws); return rc; }
     ws->ev = new (std::nothrow) std::vector<hipEvent_t>();
     if (!ws->ev) { kaamer_workspace_free(ws); return kaamer_fail(KAAMER_E_NOMEM, "event ring"); }
+    {
+        hipError_t e = hipStreamCreateWithFlags(&ws->side, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ws->ev_fork, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ws->ev_join, hipEventDisableTiming);
+        if (e != hipSuccess) { kaamer_workspace_free(ws); return kaamer_fail(KAAMER_E_HIP, "side stream: %s", hipGetErrorString(e)); }
+    }
     *out = ws;
     return KAAMER_OK;
 }
@@ -677,74 +1202,137 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     if (ix->device != ws->device) return kaamer_fail(KAAMER_E_ARG, "workspace belongs to another device");
     if (seq_type != KAAMER_PROTEIN) return kaamer_fail(KAAMER_E_ARG, "search_device: sequence type %d not supported yet", seq_type);
     if (n_seqs > ws->q_cap) return kaamer_fail(KAAMER_E_CAPACITY, "batch of %u sequences exceeds workspace max_seqs %u", n_seqs, ws->q_cap);
-    (void)seq_bytes;
+    if (seq_bytes + 64 > ws->pos_cap) return kaamer_fail(KAAMER_E_CAPACITY, "batch of %llu bytes exceeds workspace max_seq_bytes", (unsigned long long)seq_bytes);
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(ix->device));
     if (ws->n_timed >= MAX_TIMED_CALLS) ws->n_timed = 0;
-    while (ws->ev->size() < (size_t)(ws->n_timed + 1) * 4) {
+    while (ws->ev->size() < (size_t)(ws->n_timed + 1) * EV_PER_CALL) {
         hipEvent_t e;
         HIPCHK(hipEventCreate(&e));
         ws->ev->push_back(e);
     }
-    hipEvent_t *ev = ws->ev->data() + (size_t)ws->n_timed * 4;
+    hipEvent_t *ev = ws->ev->data() + (size_t)ws->n_timed * EV_PER_CALL;
     HIPCHK(hipEventRecord(ev[0], s));
-    HIPCHK(hipMemsetAsync(ws->d_pool_cursor, 0, sizeof(unsigned long long), s));
-    HIPCHK(hipMemsetAsync(ws->d_ovf_count, 0, sizeof(uint32_t), s));
-    HIPCHK(hipMemsetAsync(ws->d_counter_replicas, 0, sizeof(unsigned long long) * CTR_REPLICAS * CTR_N, s));
-    HIPCHK(hipMemsetAsync(ws->d_status, 0, sizeof(uint32_t), s));
+    if (!ws->clean) {
+        // first batch, or a previous batch did not run to its finalize kernel
+        HIPCHK(hipMemsetAsync(ws->d_pool_cursor, 0, (size_t)(POOL_SHARDS + 1) * CURSOR_STRIDE * sizeof(unsigned long long), s));
+        HIPCHK(hipMemsetAsync(ws->d_list_counts, 0, N_SMALL_SLOTS * sizeof(uint32_t), s));
+        HIPCHK(hipMemsetAsync(ws->d_counter_replicas, 0, sizeof(unsigned long long) * CTR_REPLICAS * CTR_N, s));
+        HIPCHK(hipMemsetAsync(ws->d_valid, 0, (size_t)(ws->pos_cap / 64 + 2) * sizeof(unsigned long long), s));
+    }
+    ws->clean = false;
 
+    uint32_t *status = ws->d_list_counts + SLOT_STATUS;
+    uint32_t *queue_head = ws->d_list_counts + SLOT_QUEUE_HEAD;
     const int pb = 256;
     hipLaunchKernelGGL(prep_protein_kernel, dim3((n_seqs + pb - 1) / pb > 0 ? (n_seqs + pb - 1) / pb : 1), dim3(pb), 0, s,
-                       d_seqs, d_offsets, n_seqs, ws->d_q, ws->d_nq);
+                       d_seqs, d_offsets, n_seqs, ws->s_max_size, ws->d_q, ws->d_nq, ws->d_n_pos, ws->d_valid,
+                       ws->d_lists, ws->d_list_counts, ws->q_cap, ws->d_q_start, ws->d_q_cnt);
 
-    SearchParams p;
-    p.table = reinterpret_cast<const uint4 *>(ix->d_buckets);
-    p.n_buckets = ix->hdr.n_buckets;
-    p.n_shards = ix->hdr.n_shards;
-    p.shard = ix->hdr.shard;
+    // ---- kernel P: flat probe
+    ProbeParams pp;
+    pp.table = reinterpret_cast<const uint4 *>(ix->d_buckets);
+    pp.n_buckets = ix->hdr.n_buckets;
+    pp.n_shards = ix->hdr.n_shards;
+    pp.shard = ix->hdr.shard;
+    pp.residues = d_seqs;
+    pp.invalid = ws->d_valid;
+    pp.d_n_pos = ws->d_n_pos;
+    pp.vals = ws->d_vals;
+    pp.counters = ws->d_counter_replicas;
+    uint64_t p_blocks = (seq_bytes / 64 + 1 + P_WAVES - 1) / P_WAVES;
+    if (p_blocks > (uint64_t)ws->p_grid) p_blocks = ws->p_grid;
+    if (p_blocks < 1) p_blocks = 1;
+    HIPCHK(hipEventRecord(ev[1], s));
+    hipLaunchKernelGGL(probe_kernel, dim3((unsigned)p_blocks), dim3(64 * P_WAVES), 0, s, pp);
+    HIPCHK(hipEventRecord(ev[2], s));
+    {
+        uint64_t hb = (seq_bytes + 255) / 256;
+        if (hb > (uint64_t)ws->n_cu * 8) hb = (uint64_t)ws->n_cu * 8;
+        if (hb < 1) hb = 1;
+        hipLaunchKernelGGL(heads_kernel, dim3((unsigned)hb), dim3(256), 0, s, ws->d_vals, ix->d_arena, ws->d_n_pos, ws->d_heads);
+    }
+
+    // ---- kernel C: counting tiers
+    CountParams p;
+    memset(&p, 0, sizeof p);
     p.arena = ix->d_arena;
-    p.residues = d_seqs;
-    p.q = ws->d_q;
-    p.d_nq = ws->d_nq;
-    p.min_size = 7;  // search_protein.go:74-76
+    p.vals = ws->d_vals;
+    p.heads = ws->d_heads;
+    p.list_cap = ws->q_cap;
+    p.queue_head = queue_head;
     p.q_start = ws->d_q_start;
     p.q_cnt = ws->d_q_cnt;
     p.pool_pid = ws->d_pool_pid;
     p.pool_km = ws->d_pool_km;
     p.pool_fp = ws->d_pool_fp;
-    p.pool_cap = ws->pool_cap;
+    p.pool_shard_cap = ws->pool_cap / POOL_SHARDS;
     p.pool_cursor = ws->d_pool_cursor;
-    p.ovf_list = ws->d_ovf_list;
-    p.ovf_count = ws->d_ovf_count;
-    p.ovf_cap = ws->ovf_cap;
+    p.g_keys = ws->d_g_keys;
+    p.g_cnt = ws->d_g_cnt;
+    p.g_min = ws->d_g_min;
+    p.g_slots = ws->g_slots;
+    p.g_cursor = ws->d_pool_cursor + (size_t)POOL_SHARDS * CURSOR_STRIDE;
+    p.n_proteins = ix->hdr.max_protein_id + 1u ? ix->hdr.max_protein_id + 1u : 0xFFFFFFFFu;
     p.counters = ws->d_counter_replicas;
-    p.status = ws->d_status;
+    p.status = status;
+    if (const char *e = getenv("KAAMER_ABLATE")) p.ablate = (uint32_t)atoi(e);
+    auto list_ptr = [&](int which) { return ws->d_lists + (size_t)which * ws->q_cap; };
 
-    int grid = ws->search_grid;
-    if ((uint32_t)grid > n_seqs) grid = n_seqs > 0 ? (int)n_seqs : 1;
-    HIPCHK(hipEventRecord(ev[1], s));
-    switch (ws->lds_log2) {
-    case 6: launch_search<6>(p, grid, s); break;
-    case 7: launch_search<7>(p, grid, s); break;
-    case 8: launch_search<8>(p, grid, s); break;
-    case 9: launch_search<9>(p, grid, s); break;
-    case 10: launch_search<10>(p, grid, s); break;
-    case 11: launch_search<11>(p, grid, s); break;
-    default: launch_search<12>(p, grid, s); break;
+    // the L tier (long queries) runs on the side stream beside the S tier: both are
+    // latency-bound and leave most of the chip idle when run alone
+    int l_grid = ws->l_grid;
+    if ((uint32_t)l_grid > n_seqs) l_grid = n_seqs > 0 ? (int)n_seqs : 1;
+    CountParams pl = p;
+    pl.list = list_ptr(LIST_L); pl.list_count = ws->d_list_counts + LIST_L;
+    pl.ovf_list = list_ptr(LIST_G); pl.ovf_count = ws->d_list_counts + LIST_G;
+    HIPCHK(hipEventRecord(ws->ev_fork, s));
+    HIPCHK(hipStreamWaitEvent(ws->side, ws->ev_fork, 0));
+    hipLaunchKernelGGL((count_lds_kernel<L_LOG2CAP, L_WAVES>), dim3(l_grid), dim3(64 * L_WAVES), 0, ws->side, pl);
+    HIPCHK(hipEventRecord(ws->ev_join, ws->side));
+
+    int s_grid = ws->s_grid;
+    if ((uint32_t)s_grid > n_seqs) s_grid = n_seqs > 0 ? (int)n_seqs : 1;
+    CountParams ps = p;
+    ps.list = list_ptr(LIST_S); ps.list_count = ws->d_list_counts + LIST_S;
+    ps.ovf_list = list_ptr(LIST_G); ps.ovf_count = ws->d_list_counts + LIST_G;
+    switch (ws->s_log2) {
+    case 6: launch_s<6>(ps, s_grid, s); break;
+    case 7: launch_s<7>(ps, s_grid, s); break;
+    case 8: launch_s<8>(ps, s_grid, s); break;
+    case 9: launch_s<9>(ps, s_grid, s); break;
+    case 10: launch_s<10>(ps, s_grid, s); break;
+    default: launch_s<11>(ps, s_grid, s); break;
     }
-    HIPCHK(hipEventRecord(ev[2], s));
-
-    const uint32_t nsb = (uint32_t)(((uint64_t)n_seqs + 1 + SCAN_TILE - 1) / SCAN_TILE);
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nsb), dim3(SCAN_BLOCK), 0, s, ws->d_q_cnt, ws->d_nq, ws->d_bsum);
-    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, ws->d_bsum, nsb);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(nsb), dim3(SCAN_BLOCK), 0, s, ws->d_q_cnt, ws->d_nq, ws->d_bsum, ws->d_hit_off);
-    hipLaunchKernelGGL(gather_hits_kernel, dim3(1024), dim3(256), 0, s, ws->d_nq, ws->d_hit_off, ws->d_q_start,
-                       ws->d_pool_pid, ws->d_pool_km, ws->d_pool_fp, ws->d_hit_pid, ws->d_hit_km, ws->d_hit_fp,
-                       ws->hit_cap, ws->d_status);
-    hipLaunchKernelGGL(finalize_counters_kernel, dim3(1), dim3(64), 0, s, ws->d_counter_replicas, ws->d_counters,
-                       ws->d_ovf_count, ws->d_status);
+    HIPCHK(hipStreamWaitEvent(s, ws->ev_join, 0));
+    CountParams pg = p;
+    pg.list = list_ptr(LIST_G); pg.list_count = ws->d_list_counts + LIST_G;
+    int g_grid = ws->g_grid;
+    if ((uint32_t)g_grid > n_seqs) g_grid = n_seqs > 0 ? (int)n_seqs : 1;
+    hipLaunchKernelGGL(count_global_kernel, dim3(g_grid), dim3(64 * G_WAVES), 0, s, pg);
     HIPCHK(hipEventRecord(ev[3], s));
+
+    if (n_seqs <= 8 * SCAN_TILE) {
+        hipLaunchKernelGGL(scan_single_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, ws->d_q_cnt, ws->d_nq, ws->d_hit_off);
+    } else {
+        const uint32_t nsb = (uint32_t)(((uint64_t)n_seqs + 1 + SCAN_TILE - 1) / SCAN_TILE);
+        hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nsb), dim3(SCAN_BLOCK), 0, s, ws->d_q_cnt, ws->d_nq, ws->d_bsum);
+        hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, ws->d_bsum, nsb);
+        hipLaunchKernelGGL(scan_apply_kernel, dim3(nsb), dim3(SCAN_BLOCK), 0, s, ws->d_q_cnt, ws->d_nq, ws->d_bsum, ws->d_hit_off);
+    }
+    {
+        uint32_t gb = (n_seqs + 3) / 4;  // 4 waves per block, one query per wave
+        if (gb < 1) gb = 1;
+        if (gb > (uint32_t)ws->n_cu * 64) gb = (uint32_t)ws->n_cu * 64;
+        hipLaunchKernelGGL(gather_hits_kernel, dim3(gb), dim3(256), 0, s, ws->d_nq, ws->d_hit_off, ws->d_q_start, ws->d_q_cnt,
+                           ws->d_pool_pid, ws->d_pool_km, ws->d_pool_fp, ws->d_hit_pid, ws->d_hit_km, ws->d_hit_fp,
+                           ws->hit_cap, status);
+    }
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, s, ws->d_counter_replicas, ws->d_counters, ws->d_list_counts,
+                       ws->d_status_out, ws->d_pool_cursor);
+    HIPCHK(hipEventRecord(ev[4], s));
     HIPCHK(hipGetLastError());
+    ws->clean = true;  // everything up to finalize is enqueued
     ws->n_timed++;
     ws->timed = true;
 
@@ -767,44 +1355,37 @@ int kaamer_workspace_finish(kaamer_workspace *ws, void *stream, kaamer_counters 
     HIPCHK(hipSetDevice(ws->device));
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     uint32_t status = 0;
-    HIPCHK(hipMemcpy(&status, ws->d_status, sizeof status, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(&status, ws->d_status_out, sizeof status, hipMemcpyDeviceToHost));
     kaamer_counters c;
     HIPCHK(hipMemcpy(&c, ws->d_counters, sizeof c, hipMemcpyDeviceToHost));
     if (out) *out = c;
     if (status & ST_POOL_FULL) return kaamer_fail(KAAMER_E_CAPACITY, "hit pool exhausted: raise workspace max_hits (now %llu)", (unsigned long long)ws->hit_cap);
-    if (status & ST_OVF_LIST_FULL) return kaamer_fail(KAAMER_E_CAPACITY, "overflow list exhausted");
-    if (status & ST_OVERFLOW_UNSERVED)
-        return kaamer_fail(KAAMER_E_CAPACITY, "%llu queries exceeded the on-chip counting table (%u slots): raise workspace lds_slots",
-                           (unsigned long long)c.n_overflow, 1u << ws->lds_log2);
+    if (status & ST_LIST_FULL) return kaamer_fail(KAAMER_E_CAPACITY, "tier work list exhausted");
+    if (status & ST_G_ARENA_FULL)
+        return kaamer_fail(KAAMER_E_CAPACITY, "global counting arena exhausted: raise workspace g_tier_slots (now %llu)", (unsigned long long)ws->g_slots);
     if (status) return kaamer_fail(KAAMER_E_CAPACITY, "device status 0x%x", status);
     return KAAMER_OK;
 }
 
-int kaamer_workspace_last_kernel_ms(kaamer_workspace *ws, float *search_ms, float *total_ms)
-{
-    if (!ws || !ws->timed || ws->n_timed == 0) return kaamer_fail(KAAMER_E_ARG, "no timed batch on this workspace");
-    HIPCHK(hipSetDevice(ws->device));
-    hipEvent_t *ev = ws->ev->data() + (size_t)(ws->n_timed - 1) * 4;
-    if (search_ms) HIPCHK(hipEventElapsedTime(search_ms, ev[1], ev[2]));
-    if (total_ms) HIPCHK(hipEventElapsedTime(total_ms, ev[0], ev[3]));
-    return KAAMER_OK;
-}
-
-int kaamer_workspace_kernel_ms_sum(kaamer_workspace *ws, double *search_ms, double *total_ms, uint32_t *n_calls)
+int kaamer_workspace_kernel_ms_sum(kaamer_workspace *ws, double *probe_ms, double *count_ms, double *total_ms,
+                                   uint32_t *n_calls)
 {
     if (!ws) return kaamer_fail(KAAMER_E_ARG, "kernel_ms_sum: bad argument");
     HIPCHK(hipSetDevice(ws->device));
-    double a = 0, b = 0;
+    double a = 0, b = 0, c = 0;
     for (uint32_t i = 0; i < ws->n_timed; i++) {
-        hipEvent_t *ev = ws->ev->data() + (size_t)i * 4;
-        float x = 0, y = 0;
+        hipEvent_t *ev = ws->ev->data() + (size_t)i * EV_PER_CALL;
+        float x = 0, y = 0, z = 0;
         HIPCHK(hipEventElapsedTime(&x, ev[1], ev[2]));
-        HIPCHK(hipEventElapsedTime(&y, ev[0], ev[3]));
+        HIPCHK(hipEventElapsedTime(&y, ev[2], ev[3]));
+        HIPCHK(hipEventElapsedTime(&z, ev[0], ev[4]));
         a += x;
         b += y;
+        c += z;
     }
-    if (search_ms) *search_ms = a;
-    if (total_ms) *total_ms = b;
+    if (probe_ms) *probe_ms = a;
+    if (count_ms) *count_ms = b;
+    if (total_ms) *total_ms = c;
     if (n_calls) *n_calls = ws->n_timed;
     return KAAMER_OK;
 }
@@ -824,21 +1405,16 @@ struct batch_out_owner {
     std::vector<uint32_t> pid, km, fp;
 };
 
-int kaamer_search_batch(kaamer_index *ix, const kaamer_batch_in *in, kaamer_batch_out **out)
+static int search_batch_once(kaamer_index *ix, const kaamer_batch_in *in, uint64_t max_hits, uint64_t g_slots,
+                             kaamer_batch_out **out)
 {
-    if (!ix || !in || !out || !in->offsets || (in->n_seqs && !in->seqs)) return kaamer_fail(KAAMER_E_ARG, "search_batch: bad argument");
-    *out = nullptr;
-    if (in->want_positions) return kaamer_fail(KAAMER_E_ARG, "want_positions not supported yet");
-    HIPCHK(hipSetDevice(ix->device));
     const uint64_t seq_bytes = in->offsets[in->n_seqs];
     kaamer_workspace_opts o;
     memset(&o, 0, sizeof o);
     o.max_seq_bytes = seq_bytes;
     o.max_seqs = in->n_seqs ? in->n_seqs : 1;
-    // distinct hits per query <= min(lookups, proteins)
-    uint64_t bound = 0;
-    for (uint32_t i = 0; i < in->n_seqs; i++) bound += in->offsets[i + 1] - in->offsets[i];
-    o.max_hits = bound * 8 + 4096;
+    o.max_hits = max_hits;
+    o.g_tier_slots = g_slots;
     kaamer_workspace *ws = nullptr;
     int rc = kaamer_workspace_create(ix, &o, &ws);
     if (rc) return rc;
@@ -893,6 +1469,23 @@ done:
     if (d_off) (void)hipFree(d_off);
     kaamer_workspace_free(ws);
     return rc;
+}
+
+int kaamer_search_batch(kaamer_index *ix, const kaamer_batch_in *in, kaamer_batch_out **out)
+{
+    if (!ix || !in || !out || !in->offsets || (in->n_seqs && !in->seqs)) return kaamer_fail(KAAMER_E_ARG, "search_batch: bad argument");
+    *out = nullptr;
+    if (in->want_positions) return kaamer_fail(KAAMER_E_ARG, "want_positions not supported yet");
+    HIPCHK(hipSetDevice(ix->device));
+    // The hit count of a batch is data dependent: start from a generous estimate and
+    // enlarge on KAAMER_E_CAPACITY (the device reports it; results are never partial).
+    uint64_t max_hits = in->offsets[in->n_seqs] * 8 + 65536, g_slots = 0;
+    for (int attempt = 0;; attempt++) {
+        const int rc = search_batch_once(ix, in, max_hits, g_slots, out);
+        if (rc != KAAMER_E_CAPACITY || attempt >= 6) return rc;
+        max_hits *= 4;
+        g_slots = g_slots ? g_slots * 4 : (128ull << 20);
+    }
 }
 
 void kaamer_batch_free(kaamer_batch_out *out)

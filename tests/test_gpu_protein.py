@@ -140,28 +140,59 @@ def test_shared_kmers_long_lists(klib, oracle, gpu_device):
     _check(res, _oracle_hits(oix, oracle, seqs))
 
 
-def test_counting_table_overflow_is_reported(klib, gpu_device):
-    """a query that exceeds the on-chip table must raise, never return partial counts"""
-    from kaamer_amd import abi, api
+def _device_search(ix, seqs, **ws_opts):
+    """device-resident call with explicit workspace options -> (BatchResult-like dicts, counters)"""
     import torch
-    rng = np.random.default_rng(4)
-    alpha = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
-    core = bytes(alpha[rng.integers(0, 20, 30)])
-    db = [core for _ in range(200)]                         # 200 proteins share every k-mer
-    img = api.Image.from_proteins(db)
-    ix = api.Index.from_image(img, gpu_device)
-    buf, offs = api.pack_sequences([core])
+    from kaamer_amd import api
+    buf, offs = api.pack_sequences(seqs)
     d_buf = torch.from_numpy(buf).cuda()
     d_off = torch.from_numpy(offs.view(np.int64)).cuda()
-    ws = api.Workspace(ix, len(buf), 1, lds_slots=64)       # 64 slots < 200 distinct proteins
-    ws.search_device(d_buf.data_ptr(), d_off.data_ptr(), 1, len(buf), stream=torch.cuda.current_stream().cuda_stream)
+    ws = api.Workspace(ix, len(buf), len(seqs), **ws_opts)
+    st = torch.cuda.current_stream().cuda_stream
+    r = ws.search_device(d_buf.data_ptr(), d_off.data_ptr(), len(seqs), len(buf), stream=st)
+    c = ws.finish(st)
+    hit_off = _from_ptr(r.d_hit_off, len(seqs) + 1, np.uint64)
+    n = int(hit_off[-1])
+    pid, km, fp = (_from_ptr(x, n, np.uint32) for x in (r.d_hit_pid, r.d_hit_kmatch, r.d_hit_first_pos))
+    hits = [dict(zip(pid[int(hit_off[i]):int(hit_off[i + 1])].tolist(), km[int(hit_off[i]):int(hit_off[i + 1])].tolist()))
+            for i in range(len(seqs))]
+    first = [dict(zip(pid[int(hit_off[i]):int(hit_off[i + 1])].tolist(), fp[int(hit_off[i]):int(hit_off[i + 1])].tolist()))
+             for i in range(len(seqs))]
+    return hits, first, c
+
+
+def test_tier_escalation_is_exact(klib, oracle, gpu_device):
+    """queries whose distinct hits exceed a counting tier move to the next tier (S: one wave,
+    L: 16-wave workgroup with 4096 slots, G: exactly sized table in HBM) with identical results"""
+    from kaamer_amd import abi, api
+    rng = np.random.default_rng(4)
+    alpha = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
+    core = bytes(alpha[rng.integers(0, 20, 40)])
+    long_q = bytes(alpha[rng.integers(0, 20, 300)]) + core + bytes(alpha[rng.integers(0, 20, 400)])
+    # 5000 proteins share the core with ragged ends -> 5000 distinct hits for a query holding the core
+    db = [bytes(alpha[rng.integers(0, 20, 8)]) + core[(i % 5):] + bytes(alpha[rng.integers(0, 20, 8)]) for i in range(5000)]
+    ids = (np.arange(5000, dtype=np.uint32) * 3 + 1)
+    img = api.Image.from_proteins(db, ids=ids)
+    ix = api.Index.from_image(img, gpu_device)
+    oix = oracle.Index.from_proteins(db, ids=ids)
+    seqs = [core, long_q, db[7], core[:20], b"ACDEFGHIKLMNPQRSTVWY"]
+    exp = _oracle_hits(oix, oracle, seqs)
+    assert len(exp[0][0]) == 5000
+    for opts in (dict(), dict(lds_slots=64), dict(lds_slots=2048), dict(s_tier_max_kmers=16),
+                 dict(s_tier_max_kmers=100000)):
+        hits, first, c = _device_search(ix, seqs, **opts)
+        for i, (h, f) in enumerate(exp):
+            assert hits[i] == h and first[i] == f, (opts, i)
+        assert c["n_overflow"] >= 2 and c["n_queries"] == len(seqs)
+        assert c["n_lookup"] == sum(oracle.size_in_kmer(s) for s in seqs)
+        assert c["n_post"] == sum(sum(h.values()) for h, _ in exp)
+    # an arena too small for the G tier is an error, never a partial result
     with pytest.raises(abi.KaamerError) as e:
-        ws.finish(torch.cuda.current_stream().cuda_stream)
+        _device_search(ix, seqs, g_tier_slots=4096)
     assert e.value.code == abi.E_CAPACITY
-    ws2 = api.Workspace(ix, len(buf), 1, lds_slots=512)
-    ws2.search_device(d_buf.data_ptr(), d_off.data_ptr(), 1, len(buf), stream=torch.cuda.current_stream().cuda_stream)
-    c = ws2.finish(torch.cuda.current_stream().cuda_stream)
-    assert c["n_hits"] == 200 and c["n_overflow"] == 0
+    # the host-buffer call takes the same path
+    res = ix.search(seqs)
+    _check(res, exp)
 
 
 def test_device_resident_call_and_reuse(small, oracle):
@@ -191,8 +222,8 @@ def test_device_resident_call_and_reuse(small, oracle):
         for qi, (hits, _) in enumerate(exp):
             a, b = int(hit_off[qi]), int(hit_off[qi + 1])
             assert dict(zip(pid[a:b].tolist(), km[a:b].tolist())) == hits
-        ms_search, ms_total = ws.last_kernel_ms()
-        assert 0 < ms_search <= ms_total
+        t = ws.kernel_ms_sum()
+        assert 0 < t["probe_ms"] and 0 < t["count_ms"] and t["probe_ms"] + t["count_ms"] <= t["total_ms"]
 
 
 def _from_ptr(ptr, n, dtype):
