@@ -195,6 +195,9 @@ typedef struct {
                              /* 0 = default                                    */
     uint64_t g_tier_slots;   /* HBM counting-table slots for queries whose     */
                              /* distinct hits exceed the on-chip tiers; 0 = def*/
+    int32_t seq_type;        /* KAAMER_PROTEIN, or KAAMER_NUCLEOTIDE / READS   */
+                             /* (adds the 6-frame translation buffers)         */
+    uint32_t reserved;
 } kaamer_workspace_opts;
 
 typedef struct {

@@ -63,7 +63,7 @@ class BatchOut(C.Structure):
 class WorkspaceOpts(C.Structure):
     _fields_ = [("max_seq_bytes", C.c_uint64), ("max_seqs", C.c_uint32), ("max_queries", C.c_uint32),
                 ("max_hits", C.c_uint64), ("lds_slots", C.c_uint32), ("s_tier_max_kmers", C.c_uint32),
-                ("g_tier_slots", C.c_uint64)]
+                ("g_tier_slots", C.c_uint64), ("seq_type", C.c_int32), ("reserved", C.c_uint32)]
 
 
 class DeviceResult(C.Structure):

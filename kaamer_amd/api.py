@@ -178,17 +178,20 @@ class Workspace:
     """Reusable device buffers for the device-resident call."""
 
     def __init__(self, index, max_seq_bytes, max_seqs, max_queries=0, max_hits=0, lds_slots=0,
-                 s_tier_max_kmers=0, g_tier_slots=0):
+                 s_tier_max_kmers=0, g_tier_slots=0, seq_type=abi.PROTEIN):
         self.index = index
+        self.seq_type = seq_type
         o = abi.WorkspaceOpts(max_seq_bytes, max_seqs, max_queries, max_hits, lds_slots, s_tier_max_kmers,
-                              g_tier_slots)
+                              g_tier_slots, seq_type, 0)
         h = C.c_void_p()
         abi.check(abi.lib().kaamer_workspace_create(index._h, C.byref(o), C.byref(h)))
         self._h = h
 
-    def search_device(self, d_seqs_ptr, d_offsets_ptr, n_seqs, seq_bytes, seq_type=abi.PROTEIN, stream=0):
+    def search_device(self, d_seqs_ptr, d_offsets_ptr, n_seqs, seq_bytes, seq_type=None, stream=0):
         """Enqueue one batch; pointers are raw device addresses (e.g. tensor.data_ptr()),
         `stream` a raw hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)."""
+        if seq_type is None:
+            seq_type = self.seq_type
         r = abi.DeviceResult()
         abi.check(abi.lib().kaamer_search_device(self.index._h, self._h, d_seqs_ptr, d_offsets_ptr, n_seqs,
                                                  seq_bytes, seq_type, C.c_void_p(stream), C.byref(r)))

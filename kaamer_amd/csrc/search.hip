@@ -818,6 +818,8 @@ __global__ void prep_protein_kernel(const uint8_t *seqs, const uint64_t *offsets
     }
 }
 
+#include "translate.hip.inc"
+
 // ------------------------------------------------------------------------------------
 // exclusive scan of q_cnt[0..nq) -> hit_off[0..nq]
 // ------------------------------------------------------------------------------------
@@ -997,6 +999,16 @@ struct kaamer_workspace {
     unsigned long long *d_pool_cursor;  // POOL_SHARDS pool cursors + the G arena cursor, CURSOR_STRIDE apart
     WorkItem *d_lists;                  // [N_LISTS][q_cap]
     uint4 *d_heads;                     // postings heads per residue position
+    // nucleotide / reads input: 6-frame translation products
+    bool nucleotide;
+    uint64_t aa_cap, sa_cap;
+    uint32_t *d_cnt3;                   // [3][6*max_seqs] ORF / aa / starts counts per (sequence, frame)
+    uint64_t *d_off3;                   // [3][6*max_seqs+1] their exclusive scans
+    uint32_t *d_n6;                     // device scalar 6*n_seqs
+    kaamer_query_meta *d_tmp_meta;
+    uint8_t *d_orf_aa;
+    int32_t *d_starts_alt;
+    uint32_t max_seqs;
     hipStream_t side;                   // the L tier runs beside the S tier
     hipEvent_t ev_fork, ev_join;
     uint32_t *d_list_counts;            // [N_LISTS] + queue head + status (zeroed by finalize)
@@ -1090,7 +1102,8 @@ void kaamer_workspace_free(kaamer_workspace *ws)
 {
     if (!ws) return;
     (void)hipSetDevice(ws->device);
-    void *bufs[] = { ws->d_q, ws->d_nq, ws->d_n_pos, ws->d_valid, ws->d_vals, ws->d_heads, ws->d_q_start, ws->d_q_cnt, ws->d_pool_pid,
+    void *bufs[] = { ws->d_q, ws->d_nq, ws->d_n_pos, ws->d_valid, ws->d_vals, ws->d_heads, ws->d_cnt3, ws->d_off3, ws->d_n6,
+                     ws->d_tmp_meta, ws->d_orf_aa, ws->d_starts_alt, ws->d_q_start, ws->d_q_cnt, ws->d_pool_pid,
                      ws->d_pool_km, ws->d_pool_fp, ws->d_pool_cursor, ws->d_lists, ws->d_list_counts, ws->d_status_out, ws->d_g_keys,
                      ws->d_g_cnt, ws->d_g_min, ws->d_counter_replicas, ws->d_counters, ws->d_bsum, ws->d_hit_off,
                      ws->d_hit_pid, ws->d_hit_km, ws->d_hit_fp };
@@ -1115,9 +1128,21 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     memset(ws, 0, sizeof *ws);
     ws->device = ix->device;
     ws->opts = *opts;
-    ws->q_cap = opts->max_queries ? opts->max_queries : opts->max_seqs;
+    ws->nucleotide = opts->seq_type == KAAMER_NUCLEOTIDE || opts->seq_type == KAAMER_READS;
+    ws->max_seqs = opts->max_seqs ? opts->max_seqs : 1;
+    if (ws->nucleotide) {
+        // six frames of len/3 codons: at most 2 amino acids per nucleotide, an ORF needs >= 21 of them
+        ws->aa_cap = 2 * opts->max_seq_bytes + 64;
+        ws->sa_cap = ws->aa_cap;
+        uint64_t qc = opts->max_queries ? opts->max_queries : (uint64_t)ws->max_seqs * 4 + opts->max_seq_bytes / 32 + 64;
+        if (qc > 0xFFFFFFF0ull) qc = 0xFFFFFFF0ull;
+        ws->q_cap = (uint32_t)qc;
+        ws->pos_cap = ws->aa_cap + 64;
+    } else {
+        ws->q_cap = opts->max_queries ? opts->max_queries : ws->max_seqs;
+        ws->pos_cap = opts->max_seq_bytes + 64;
+    }
     if (ws->q_cap < 1) ws->q_cap = 1;
-    ws->pos_cap = opts->max_seq_bytes + 64;
     ws->hit_cap = opts->max_hits ? opts->max_hits : (uint64_t)ws->q_cap * 256 + (1u << 20);
     const uint32_t slots = opts->lds_slots ? opts->lds_slots : 512;
     uint32_t l2 = 6;
@@ -1155,13 +1180,26 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     // every resident S wave may hold one partly used chunk; shards fill unevenly (+25 %)
     ws->pool_cap = ws->hit_cap + ws->hit_cap / 4 + (uint64_t)ws->s_grid * POOL_CHUNK + POOL_SHARDS * 4096ull;
     ws->pool_cap = (ws->pool_cap + POOL_SHARDS - 1) / POOL_SHARDS * POOL_SHARDS;
-    ws->n_scan_blocks = (uint32_t)(((uint64_t)ws->q_cap + 1 + SCAN_TILE - 1) / SCAN_TILE);
+    {
+        uint64_t n = ws->q_cap;
+        if (ws->nucleotide && (uint64_t)ws->max_seqs * 6 > n) n = (uint64_t)ws->max_seqs * 6;
+        ws->n_scan_blocks = (uint32_t)((n + 1 + SCAN_TILE - 1) / SCAN_TILE);
+    }
     rc = dev_alloc(&ws->d_q, ws->q_cap);
     if (!rc) rc = dev_alloc(&ws->d_nq, 1);
     if (!rc) rc = dev_alloc(&ws->d_n_pos, 1);
     if (!rc) rc = dev_alloc(&ws->d_valid, (size_t)(ws->pos_cap / 64 + 2));
     if (!rc) rc = dev_alloc(&ws->d_vals, (size_t)ws->pos_cap);
     if (!rc) rc = dev_alloc(&ws->d_heads, (size_t)ws->pos_cap);
+    if (!rc && ws->nucleotide) {
+        const size_t n6 = (size_t)ws->max_seqs * 6;
+        rc = dev_alloc(&ws->d_cnt3, 3 * n6);
+        if (!rc) rc = dev_alloc(&ws->d_off3, 3 * (n6 + 1));
+        if (!rc) rc = dev_alloc(&ws->d_n6, 1);
+        if (!rc) rc = dev_alloc(&ws->d_tmp_meta, ws->q_cap);
+        if (!rc) rc = dev_alloc(&ws->d_orf_aa, (size_t)ws->aa_cap + 64);
+        if (!rc) rc = dev_alloc(&ws->d_starts_alt, (size_t)ws->sa_cap + 64);
+    }
     if (!rc) rc = dev_alloc(&ws->d_q_start, ws->q_cap);
     if (!rc) rc = dev_alloc(&ws->d_q_cnt, ws->q_cap);
     if (!rc) rc = dev_alloc(&ws->d_pool_pid, ws->pool_cap);
@@ -1200,9 +1238,11 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
 {
     if (!ix || !ws || !out || (n_seqs && (!d_seqs || !d_offsets))) return kaamer_fail(KAAMER_E_ARG, "search_device: bad argument");
     if (ix->device != ws->device) return kaamer_fail(KAAMER_E_ARG, "workspace belongs to another device");
-    if (seq_type != KAAMER_PROTEIN) return kaamer_fail(KAAMER_E_ARG, "search_device: sequence type %d not supported yet", seq_type);
-    if (n_seqs > ws->q_cap) return kaamer_fail(KAAMER_E_CAPACITY, "batch of %u sequences exceeds workspace max_seqs %u", n_seqs, ws->q_cap);
-    if (seq_bytes + 64 > ws->pos_cap) return kaamer_fail(KAAMER_E_CAPACITY, "batch of %llu bytes exceeds workspace max_seq_bytes", (unsigned long long)seq_bytes);
+    const bool nucl = seq_type == KAAMER_NUCLEOTIDE || seq_type == KAAMER_READS;
+    if (!nucl && seq_type != KAAMER_PROTEIN) return kaamer_fail(KAAMER_E_ARG, "search_device: unknown sequence type %d", seq_type);
+    if (nucl != ws->nucleotide) return kaamer_fail(KAAMER_E_ARG, "workspace was created for %s input", ws->nucleotide ? "nucleotide" : "protein");
+    if (n_seqs > ws->max_seqs) return kaamer_fail(KAAMER_E_CAPACITY, "batch of %u sequences exceeds workspace max_seqs %u", n_seqs, ws->max_seqs);
+    if (seq_bytes > ws->opts.max_seq_bytes) return kaamer_fail(KAAMER_E_CAPACITY, "batch of %llu bytes exceeds workspace max_seq_bytes", (unsigned long long)seq_bytes);
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(ix->device));
     if (ws->n_timed >= MAX_TIMED_CALLS) ws->n_timed = 0;
@@ -1225,9 +1265,48 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     uint32_t *status = ws->d_list_counts + SLOT_STATUS;
     uint32_t *queue_head = ws->d_list_counts + SLOT_QUEUE_HEAD;
     const int pb = 256;
-    hipLaunchKernelGGL(prep_protein_kernel, dim3((n_seqs + pb - 1) / pb > 0 ? (n_seqs + pb - 1) / pb : 1), dim3(pb), 0, s,
-                       d_seqs, d_offsets, n_seqs, ws->s_max_size, ws->d_q, ws->d_nq, ws->d_n_pos, ws->d_valid,
-                       ws->d_lists, ws->d_list_counts, ws->q_cap, ws->d_q_start, ws->d_q_cnt);
+    const uint8_t *residues = d_seqs;   // what kernel P reads: the protein records, or the ORF amino acids
+    uint64_t pos_bound = seq_bytes;     // host-side bound of the residue positions (grid sizing only)
+    uint32_t nq_bound = n_seqs;         // host-side bound of the number of queries
+    if (!nucl) {
+        hipLaunchKernelGGL(prep_protein_kernel, dim3((n_seqs + pb - 1) / pb > 0 ? (n_seqs + pb - 1) / pb : 1), dim3(pb), 0, s,
+                           d_seqs, d_offsets, n_seqs, ws->s_max_size, ws->d_q, ws->d_nq, ws->d_n_pos, ws->d_valid,
+                           ws->d_lists, ws->d_list_counts, ws->q_cap, ws->d_q_start, ws->d_q_cnt);
+    } else {
+        // 6-frame translation: count, scan, write, order (translate.hip.inc)
+        const size_t n6 = (size_t)n_seqs * 6, cap6 = (size_t)ws->max_seqs * 6;
+        TranslateParams tp;
+        memset(&tp, 0, sizeof tp);
+        tp.seqs = d_seqs; tp.offsets = d_offsets; tp.n_seqs = n_seqs;
+        tp.cnt_orf = ws->d_cnt3; tp.cnt_aa = ws->d_cnt3 + cap6; tp.cnt_sa = ws->d_cnt3 + 2 * cap6;
+        tp.off_orf = ws->d_off3; tp.off_aa = ws->d_off3 + (cap6 + 1); tp.off_sa = ws->d_off3 + 2 * (cap6 + 1);
+        tp.tmp_meta = ws->d_tmp_meta; tp.orf_aa = ws->d_orf_aa; tp.starts_alt = ws->d_starts_alt;
+        tp.q_cap = ws->q_cap; tp.aa_cap = ws->aa_cap; tp.sa_cap = ws->sa_cap; tp.status = status;
+        int tgrid = ws->n_cu * 16;
+        if ((uint32_t)tgrid > n_seqs) tgrid = n_seqs > 0 ? (int)n_seqs : 1;
+        tp.d_n6 = ws->d_n6;
+        hipLaunchKernelGGL(translate_kernel<false>, dim3(tgrid), dim3(64), 0, s, tp);
+        const uint32_t nsb6 = (uint32_t)((n6 + 1 + SCAN_TILE - 1) / SCAN_TILE);
+        for (int a = 0; a < 3; a++) {
+            const uint32_t *cnt = ws->d_cnt3 + a * cap6;
+            uint64_t *off = ws->d_off3 + a * (cap6 + 1);
+            if (n6 <= 8 * (size_t)SCAN_TILE) {
+                hipLaunchKernelGGL(scan_single_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, cnt, ws->d_n6, off);
+            } else {
+                hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nsb6), dim3(SCAN_BLOCK), 0, s, cnt, ws->d_n6, ws->d_bsum);
+                hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, ws->d_bsum, nsb6);
+                hipLaunchKernelGGL(scan_apply_kernel, dim3(nsb6), dim3(SCAN_BLOCK), 0, s, cnt, ws->d_n6, ws->d_bsum, off);
+            }
+        }
+        hipLaunchKernelGGL(translate_kernel<true>, dim3(tgrid), dim3(64), 0, s, tp);
+        hipLaunchKernelGGL(orf_order_kernel, dim3(ws->n_cu * 4), dim3(256), 0, s, ws->d_tmp_meta, tp.off_orf, n_seqs, ws->d_q,
+                           ws->d_nq, ws->d_n_pos, tp.off_aa, (uint64_t)ws->q_cap, status);
+        hipLaunchKernelGGL(prep_orf_kernel, dim3(ws->n_cu * 4), dim3(pb), 0, s, ws->d_q, ws->d_nq, ws->s_max_size, ws->d_valid,
+                           ws->d_n_pos, ws->d_lists, ws->d_list_counts, ws->q_cap, ws->d_q_start, ws->d_q_cnt);
+        residues = ws->d_orf_aa;
+        pos_bound = ws->aa_cap;
+        nq_bound = ws->q_cap;
+    }
 
     // ---- kernel P: flat probe
     ProbeParams pp;
@@ -1235,19 +1314,19 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     pp.n_buckets = ix->hdr.n_buckets;
     pp.n_shards = ix->hdr.n_shards;
     pp.shard = ix->hdr.shard;
-    pp.residues = d_seqs;
+    pp.residues = residues;
     pp.invalid = ws->d_valid;
     pp.d_n_pos = ws->d_n_pos;
     pp.vals = ws->d_vals;
     pp.counters = ws->d_counter_replicas;
-    uint64_t p_blocks = (seq_bytes / 64 + 1 + P_WAVES - 1) / P_WAVES;
+    uint64_t p_blocks = (pos_bound / 64 + 1 + P_WAVES - 1) / P_WAVES;
     if (p_blocks > (uint64_t)ws->p_grid) p_blocks = ws->p_grid;
     if (p_blocks < 1) p_blocks = 1;
     HIPCHK(hipEventRecord(ev[1], s));
     hipLaunchKernelGGL(probe_kernel, dim3((unsigned)p_blocks), dim3(64 * P_WAVES), 0, s, pp);
     HIPCHK(hipEventRecord(ev[2], s));
     {
-        uint64_t hb = (seq_bytes + 255) / 256;
+        uint64_t hb = (pos_bound + 255) / 256;
         if (hb > (uint64_t)ws->n_cu * 8) hb = (uint64_t)ws->n_cu * 8;
         if (hb < 1) hb = 1;
         hipLaunchKernelGGL(heads_kernel, dim3((unsigned)hb), dim3(256), 0, s, ws->d_vals, ix->d_arena, ws->d_n_pos, ws->d_heads);
@@ -1282,7 +1361,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     // the L tier (long queries) runs on the side stream beside the S tier: both are
     // latency-bound and leave most of the chip idle when run alone
     int l_grid = ws->l_grid;
-    if ((uint32_t)l_grid > n_seqs) l_grid = n_seqs > 0 ? (int)n_seqs : 1;
+    if ((uint32_t)l_grid > nq_bound) l_grid = nq_bound > 0 ? (int)nq_bound : 1;
     CountParams pl = p;
     pl.list = list_ptr(LIST_L); pl.list_count = ws->d_list_counts + LIST_L;
     pl.ovf_list = list_ptr(LIST_G); pl.ovf_count = ws->d_list_counts + LIST_G;
@@ -1292,7 +1371,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     HIPCHK(hipEventRecord(ws->ev_join, ws->side));
 
     int s_grid = ws->s_grid;
-    if ((uint32_t)s_grid > n_seqs) s_grid = n_seqs > 0 ? (int)n_seqs : 1;
+    if ((uint32_t)s_grid > nq_bound) s_grid = nq_bound > 0 ? (int)nq_bound : 1;
     CountParams ps = p;
     ps.list = list_ptr(LIST_S); ps.list_count = ws->d_list_counts + LIST_S;
     ps.ovf_list = list_ptr(LIST_G); ps.ovf_count = ws->d_list_counts + LIST_G;
@@ -1308,20 +1387,20 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     CountParams pg = p;
     pg.list = list_ptr(LIST_G); pg.list_count = ws->d_list_counts + LIST_G;
     int g_grid = ws->g_grid;
-    if ((uint32_t)g_grid > n_seqs) g_grid = n_seqs > 0 ? (int)n_seqs : 1;
+    if ((uint32_t)g_grid > nq_bound) g_grid = nq_bound > 0 ? (int)nq_bound : 1;
     hipLaunchKernelGGL(count_global_kernel, dim3(g_grid), dim3(64 * G_WAVES), 0, s, pg);
     HIPCHK(hipEventRecord(ev[3], s));
 
-    if (n_seqs <= 8 * SCAN_TILE) {
+    if (nq_bound <= 8 * SCAN_TILE) {
         hipLaunchKernelGGL(scan_single_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, ws->d_q_cnt, ws->d_nq, ws->d_hit_off);
     } else {
-        const uint32_t nsb = (uint32_t)(((uint64_t)n_seqs + 1 + SCAN_TILE - 1) / SCAN_TILE);
+        const uint32_t nsb = (uint32_t)(((uint64_t)nq_bound + 1 + SCAN_TILE - 1) / SCAN_TILE);
         hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nsb), dim3(SCAN_BLOCK), 0, s, ws->d_q_cnt, ws->d_nq, ws->d_bsum);
         hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, ws->d_bsum, nsb);
         hipLaunchKernelGGL(scan_apply_kernel, dim3(nsb), dim3(SCAN_BLOCK), 0, s, ws->d_q_cnt, ws->d_nq, ws->d_bsum, ws->d_hit_off);
     }
     {
-        uint32_t gb = (n_seqs + 3) / 4;  // 4 waves per block, one query per wave
+        uint32_t gb = (nq_bound + 3) / 4;  // 4 waves per block, one query per wave
         if (gb < 1) gb = 1;
         if (gb > (uint32_t)ws->n_cu * 64) gb = (uint32_t)ws->n_cu * 64;
         hipLaunchKernelGGL(gather_hits_kernel, dim3(gb), dim3(256), 0, s, ws->d_nq, ws->d_hit_off, ws->d_q_start, ws->d_q_cnt,
@@ -1343,8 +1422,8 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     out->d_hit_pid = ws->d_hit_pid;
     out->d_hit_kmatch = ws->d_hit_km;
     out->d_hit_first_pos = ws->d_hit_fp;
-    out->d_orf_aa = nullptr;
-    out->d_starts_alt = nullptr;
+    out->d_orf_aa = nucl ? ws->d_orf_aa : nullptr;
+    out->d_starts_alt = nucl ? ws->d_starts_alt : nullptr;
     out->d_counters = ws->d_counters;
     return KAAMER_OK;
 }
@@ -1361,6 +1440,8 @@ int kaamer_workspace_finish(kaamer_workspace *ws, void *stream, kaamer_counters 
     if (out) *out = c;
     if (status & ST_POOL_FULL) return kaamer_fail(KAAMER_E_CAPACITY, "hit pool exhausted: raise workspace max_hits (now %llu)", (unsigned long long)ws->hit_cap);
     if (status & ST_LIST_FULL) return kaamer_fail(KAAMER_E_CAPACITY, "tier work list exhausted");
+    if (status & (ST_QUERY_CAP | ST_AA_CAP))
+        return kaamer_fail(KAAMER_E_CAPACITY, "more ORFs than the workspace holds: raise workspace max_queries (now %u)", ws->q_cap);
     if (status & ST_G_ARENA_FULL)
         return kaamer_fail(KAAMER_E_CAPACITY, "global counting arena exhausted: raise workspace g_tier_slots (now %llu)", (unsigned long long)ws->g_slots);
     if (status) return kaamer_fail(KAAMER_E_CAPACITY, "device status 0x%x", status);
@@ -1403,10 +1484,12 @@ struct batch_out_owner {
     std::vector<kaamer_query_meta> q;
     std::vector<uint64_t> hit_off;
     std::vector<uint32_t> pid, km, fp;
+    std::vector<uint8_t> orf_aa;
+    std::vector<int32_t> starts_alt;
 };
 
 static int search_batch_once(kaamer_index *ix, const kaamer_batch_in *in, uint64_t max_hits, uint64_t g_slots,
-                             kaamer_batch_out **out)
+                             uint32_t max_queries, kaamer_batch_out **out)
 {
     const uint64_t seq_bytes = in->offsets[in->n_seqs];
     kaamer_workspace_opts o;
@@ -1415,6 +1498,8 @@ static int search_batch_once(kaamer_index *ix, const kaamer_batch_in *in, uint64
     o.max_seqs = in->n_seqs ? in->n_seqs : 1;
     o.max_hits = max_hits;
     o.g_tier_slots = g_slots;
+    o.seq_type = in->seq_type;
+    o.max_queries = max_queries;
     kaamer_workspace *ws = nullptr;
     int rc = kaamer_workspace_create(ix, &o, &ws);
     if (rc) return rc;
@@ -1452,6 +1537,16 @@ static int search_batch_once(kaamer_index *ix, const kaamer_batch_in *in, uint64
             if (e == hipSuccess) e = hipMemcpy(bo->fp.data(), dr.d_hit_first_pos, n_hits * 4, hipMemcpyDeviceToHost);
         }
     }
+    if (e == hipSuccess && ws->nucleotide) {
+        unsigned long long n_aa = 0;
+        uint64_t n_sa = 0;
+        e = hipMemcpy(&n_aa, ws->d_n_pos, sizeof n_aa, hipMemcpyDeviceToHost);
+        const size_t cap6 = (size_t)ws->max_seqs * 6;
+        if (e == hipSuccess) e = hipMemcpy(&n_sa, ws->d_off3 + 2 * (cap6 + 1) + (size_t)in->n_seqs * 6, sizeof n_sa, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) { bo->orf_aa.resize(n_aa + 1); bo->starts_alt.resize(n_sa + 1); }
+        if (e == hipSuccess && n_aa) e = hipMemcpy(bo->orf_aa.data(), dr.d_orf_aa, n_aa, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && n_sa) e = hipMemcpy(bo->starts_alt.data(), dr.d_starts_alt, n_sa * sizeof(int32_t), hipMemcpyDeviceToHost);
+    }
     if (e != hipSuccess) { rc = kaamer_fail(KAAMER_E_HIP, "D2H: %s", hipGetErrorString(e)); goto done; }
     memset(&bo->pub, 0, sizeof bo->pub);
     bo->pub.n_queries = nq;
@@ -1460,6 +1555,7 @@ static int search_batch_once(kaamer_index *ix, const kaamer_batch_in *in, uint64
     bo->pub.hit_pid = bo->pid.data();
     bo->pub.hit_kmatch = bo->km.data();
     bo->pub.hit_first_pos = bo->fp.data();
+    if (ws->nucleotide) { bo->pub.orf_aa = bo->orf_aa.data(); bo->pub.starts_alt = bo->starts_alt.data(); }
     bo->pub.counters = c;
     *out = &bo->pub;
     bo = nullptr;
@@ -1480,11 +1576,17 @@ int kaamer_search_batch(kaamer_index *ix, const kaamer_batch_in *in, kaamer_batc
     // The hit count of a batch is data dependent: start from a generous estimate and
     // enlarge on KAAMER_E_CAPACITY (the device reports it; results are never partial).
     uint64_t max_hits = in->offsets[in->n_seqs] * 8 + 65536, g_slots = 0;
+    uint32_t max_queries = 0;
+    const bool nucl = in->seq_type == KAAMER_NUCLEOTIDE || in->seq_type == KAAMER_READS;
     for (int attempt = 0;; attempt++) {
-        const int rc = search_batch_once(ix, in, max_hits, g_slots, out);
+        const int rc = search_batch_once(ix, in, max_hits, g_slots, max_queries, out);
         if (rc != KAAMER_E_CAPACITY || attempt >= 6) return rc;
         max_hits *= 4;
         g_slots = g_slots ? g_slots * 4 : (128ull << 20);
+        if (nucl) {  // hard bound: a frame of n codons holds at most n/21 + 1 ORFs
+            const uint64_t hard = in->offsets[in->n_seqs] / 10 + (uint64_t)in->n_seqs * 6 + 64;
+            max_queries = (uint32_t)(hard > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : hard);
+        }
     }
 }
 
