@@ -45,7 +45,7 @@ def log(*a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(oix, queries, seconds=12.0, threads=None):
+def cpu_baseline(oix, queries, seconds=12.0, threads=None, kind="protein"):
     """The CPU restatement of the reference algorithm (oracle/, kind "port"),
     multi-threaded across queries like the reference's nbOfThreads workers
     (search_protein.go:58), on a bounded sample of the same batch."""
@@ -64,7 +64,7 @@ def cpu_baseline(oix, queries, seconds=12.0, threads=None):
             if b >= nq:
                 b = tid * block
             e = min(nq, b + block)
-            r = oix.batch(queries, "protein", b, e)   # ctypes releases the GIL
+            r = oix.batch(queries, kind, b, e)   # ctypes releases the GIL
             lookups += r["n_lookup"]
             nqd += e - b
             b += threads * block
@@ -76,8 +76,8 @@ def cpu_baseline(oix, queries, seconds=12.0, threads=None):
     lookups = sum(p[0] for p in parts)
     nqd = sum(p[1] for p in parts)
     return {"value": lookups / dt, "unit": "k-mer lookups/s", "cores": threads, "kind": "port",
-            "sample": "%d queries (%d lookups) in %.1f s, cycling the timed batch of %d queries; oracle = sorted "
-                      "(key,id) array + binary search, not Badger" % (nqd, lookups, dt, nq),
+            "sample": "%d %s (%d lookups) in %.1f s, cycling the timed batch of %d; oracle = sorted "
+                      "(key,id) array + binary search, not Badger" % (nqd, "reads" if kind == "reads" else "queries", lookups, dt, nq),
             "queries_per_s": nqd / dt}
 
 
@@ -87,7 +87,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--db-proteins", type=int, default=560000)
-    ap.add_argument("--queries", type=int, default=10000)
+    ap.add_argument("--workload", choices=["protein", "reads"], default="protein",
+                    help="protein = BASELINE configs[1] (default); reads = configs[2]: 150-nt reads, 6-frame path")
+    ap.add_argument("--queries", type=int, default=0, help="sequences per batch (default 10000 proteins / 1000000 reads)")
     ap.add_argument("--lds-slots", type=int, default=0)
     ap.add_argument("--load-factor", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -95,6 +97,8 @@ def main():
     ap.add_argument("--check", type=int, default=50, help="queries checked against the oracle after timing")
     args = ap.parse_args()
 
+    if args.queries <= 0:
+        args.queries = 10000 if args.workload == "protein" else 1000000
     _tame_malloc()
     import numpy as np
     import torch
@@ -124,11 +128,18 @@ def main():
     log("index resident in HBM (%.2f GB) in %.1fs" % ((st["n_buckets"] * 64 + st["arena_words"] * 4) / 1e9, time.time() - t0))
 
     # every rank searches its own batch (replicas): same generator, rank-specific seed
-    q = workload.make_protein_queries(db, args.queries, seed=workload.SEED + 1 + 1000 * rank)
+    from kaamer_amd import abi
+    reads = args.workload == "reads"
+    if reads:
+        q = workload.make_reads(db, args.queries, seed=workload.SEED + 2 + 1000 * rank)
+    else:
+        q = workload.make_protein_queries(db, args.queries, seed=workload.SEED + 1 + 1000 * rank)
     qbuf, qoff = q
     d_buf = torch.from_numpy(qbuf).cuda()
     d_off = torch.from_numpy(qoff.view(np.int64)).cuda()
-    ws = api.Workspace(ix, len(qbuf), args.queries, lds_slots=args.lds_slots)
+    ws = api.Workspace(ix, len(qbuf), args.queries, lds_slots=args.lds_slots,
+                       seq_type=abi.READS if reads else abi.PROTEIN,
+                       max_hits=(64 << 20) if reads else 0)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
@@ -154,7 +165,7 @@ def main():
     n_calls = max(tm["calls"], 1)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    lk = torch.tensor([float(counters["n_lookup"]), float(counters["n_queries"])], dtype=torch.float64, device="cuda")
+    lk = torch.tensor([float(counters["n_lookup"]), float(args.queries)], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(lk, op=dist.ReduceOp.SUM)
@@ -169,7 +180,7 @@ def main():
     #   count kernels: 4 B per position (val read back) + 4 B per arena word that must be read
     #                  (list header + ids) + 12 B per emitted hit (pid, kmatch, first_pos)
     c = counters
-    n_pos = int(qoff[-1])
+    n_pos = int(c["n_in"]) if reads else int(qoff[-1])  # residue positions kernel P walks (reads: ORF amino acids)
     probe_bytes = n_pos + n_pos // 8 + 64 * c["n_probe"] + 4 * n_pos
     count_bytes = 4 * n_pos + 4 * (c["n_lists"] + c["n_list_ids"]) + 12 * c["n_hits"]
     probe_s = tm["probe_ms"] / n_calls / 1e3
@@ -191,9 +202,10 @@ def main():
         "unit": "k-mer lookups/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-        "config": {"workload": "configs[1]: Swiss-Prot-sized synthetic DB (%d proteins, %d residues, %d distinct "
-                               "7-mers) resident in HBM; %d protein queries per GPU per step"
-                               % (args.db_proteins, int(db[1][-1]), st["n_keys"], args.queries),
+        "config": {"workload": ("configs[2]: 6-frame path, %d synthetic 150-nt reads per GPU per step vs " if reads else
+                                "configs[1]: %d protein queries per GPU per step vs ") % args.queries +
+                               "Swiss-Prot-sized synthetic DB (%d proteins, %d residues, %d distinct 7-mers) resident in HBM"
+                               % (args.db_proteins, int(db[1][-1]), st["n_keys"]),
                    "parallelism": "replicas x%d (no collective)" % world if world > 1 else "single GPU",
                    "seed": workload.SEED},
         "query_seqs_per_s": queries_per_step * args.steps / elapsed,
@@ -210,17 +222,26 @@ def main():
             log("oracle index built in %.1fs" % (time.time() - t0))
             if args.check:
                 sub = workload.unpack(q)[:args.check]
-                res = ix.search(sub)
-                for i, s in enumerate(sub):
-                    exp = {}
-                    if O.size_in_kmer(s) >= 7:
-                        pid, km, _ = oix.search(s)
-                        exp = dict(zip(pid.tolist(), km.tolist()))
-                    assert res.hits(i) == exp, "bench: query %d differs from the oracle" % i
+                res = ix.search(sub, seq_type=abi.READS if reads else abi.PROTEIN)
+                if reads:
+                    qi = 0
+                    for s in sub:
+                        for o in O.get_orfs(s):
+                            pid, km, _ = oix.search(o["seq"])
+                            assert res.hits(qi) == dict(zip(pid.tolist(), km.tolist())), "bench: ORF %d differs from the oracle" % qi
+                            qi += 1
+                    assert qi == res.n_queries
+                else:
+                    for i, s in enumerate(sub):
+                        exp = {}
+                        if O.size_in_kmer(s) >= 7:
+                            pid, km, _ = oix.search(s)
+                            exp = dict(zip(pid.tolist(), km.tolist()))
+                        assert res.hits(i) == exp, "bench: query %d differs from the oracle" % i
                 out["parity_checked_queries"] = len(sub)
                 log("parity: %d queries of the timed batch bit-exact vs oracle" % len(sub))
             if want_cpu:
-                out["cpu_baseline"] = cpu_baseline(oix, q, seconds=args.cpu_seconds)
+                out["cpu_baseline"] = cpu_baseline(oix, q, seconds=args.cpu_seconds, kind="reads" if reads else "protein")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
