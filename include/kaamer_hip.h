@@ -197,7 +197,9 @@ typedef struct {
                              /* distinct hits exceed the on-chip tiers; 0 = def*/
     int32_t seq_type;        /* KAAMER_PROTEIN, or KAAMER_NUCLEOTIDE / READS   */
                              /* (adds the 6-frame translation buffers)         */
-    uint32_t reserved;
+    uint32_t first_pos;      /* hit_first_pos: 0 = as the reference fills      */
+                             /* PositionHits (nucleotide/reads only,           */
+                             /* search.go:416), 1 = always, 2 = never (zeros)  */
 } kaamer_workspace_opts;
 
 typedef struct {

@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkaamer_hip.so")
+# KAAMER_LIB points at an alternative build of the same library (tuning experiments only)
+LIB_PATH = os.environ.get("KAAMER_LIB") or os.path.join(_HERE, "libkaamer_hip.so")
 
 OK, E_ARG, E_IO, E_NOMEM, E_HIP, E_CAPACITY, E_FORMAT = 0, -1, -2, -3, -4, -5, -6
 NUCLEOTIDE, PROTEIN, READS = 0, 1, 2
@@ -63,7 +64,7 @@ class BatchOut(C.Structure):
 class WorkspaceOpts(C.Structure):
     _fields_ = [("max_seq_bytes", C.c_uint64), ("max_seqs", C.c_uint32), ("max_queries", C.c_uint32),
                 ("max_hits", C.c_uint64), ("lds_slots", C.c_uint32), ("s_tier_max_kmers", C.c_uint32),
-                ("g_tier_slots", C.c_uint64), ("seq_type", C.c_int32), ("reserved", C.c_uint32)]
+                ("g_tier_slots", C.c_uint64), ("seq_type", C.c_int32), ("first_pos", C.c_uint32)]
 
 
 class DeviceResult(C.Structure):

@@ -178,11 +178,11 @@ class Workspace:
     """Reusable device buffers for the device-resident call."""
 
     def __init__(self, index, max_seq_bytes, max_seqs, max_queries=0, max_hits=0, lds_slots=0,
-                 s_tier_max_kmers=0, g_tier_slots=0, seq_type=abi.PROTEIN):
+                 s_tier_max_kmers=0, g_tier_slots=0, seq_type=abi.PROTEIN, first_pos=0):
         self.index = index
         self.seq_type = seq_type
         o = abi.WorkspaceOpts(max_seq_bytes, max_seqs, max_queries, max_hits, lds_slots, s_tier_max_kmers,
-                              g_tier_slots, seq_type, 0)
+                              g_tier_slots, seq_type, first_pos)
         h = C.c_void_p()
         abi.check(abi.lib().kaamer_workspace_create(index._h, C.byref(o), C.byref(h)))
         self._h = h

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libkaamer_hip.so")
 SOURCES = ["search.hip", "builder.cpp", "host_search.cpp"]
-HEADERS = ["kaamer_layout.h", "kaamer_internal.h", os.path.join("..", "..", "include", "kaamer_hip.h")]
+HEADERS = ["kaamer_layout.h", "kaamer_internal.h", "translate.hip.inc", os.path.join("..", "..", "include", "kaamer_hip.h")]
 ARCH = "gfx950"
 
 
@@ -37,7 +37,8 @@ def build(force=False, verbose=False):
         return LIB
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
-           "-Wno-unused-function", "-o", LIB + ".tmp"] + srcs + ["-lpthread"]
+           "-Wno-unused-function"] + os.environ.get("KAAMER_EXTRA_CFLAGS", "").split() + \
+          ["-o", LIB + ".tmp"] + srcs + ["-lpthread"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -87,6 +87,12 @@ struct alignas(16) WorkItem {
 #define L_WAVES 8
 #define L_LOG2CAP 12
 #define G_WAVES 16
+#ifndef S_MIN_WAVES
+#define S_MIN_WAVES 1
+#endif
+#ifndef L_MIN_WAVES
+#define L_MIN_WAVES 1
+#endif
 #ifndef S_NWIN
 #define S_NWIN 3
 #endif
@@ -249,10 +255,17 @@ __global__ __launch_bounds__(256) void heads_kernel(const uint32_t *vals, const 
 // ====================================================================================
 // Kernel C — per-query counting (postings expansion + Counter increments)
 // ====================================================================================
+struct QInfo;
 struct CountParams {
     const uint32_t *arena;
     const uint32_t *vals;  // from kernel P, indexed like the residue buffer
     const uint4 *heads;    // from kernel H: {count, id0, id1, id2} per position
+    // query groups (count_group.hip.inc)
+    const struct QInfo *qinfo;
+    const uint64_t *slot_off;   // exclusive scan of the table capacities
+    uint32_t *group_first;      // first query of each group (self-cleaning)
+    const uint32_t *d_n_groups;
+    const uint32_t *d_nq;
     // tier input / overflow output lists
     const WorkItem *list;
     const uint32_t *list_count;
@@ -273,11 +286,29 @@ struct CountParams {
     uint32_t n_proteins;
     unsigned long long *counters;  // [CTR_REPLICAS][CTR_N]
     uint32_t *status;
+    unsigned long long *stamps;  // diagnostic build only
     uint32_t ablate;  // timing experiments only (KAAMER_ABLATE): 1 no table adds, 2 no leftover loads, 4 no hit stores
 };
 
+// ---- diagnostic build only (-DKAAMER_STAMPS): where a counting workgroup spends its cycles.
+// The stamped build drains the memory queues at every stamp, so read its SHARES, never its
+// run time; no stamp executes in the product build.
+#ifdef KAAMER_STAMPS
+#define KSTAMP_N 10
+struct KStamps { unsigned long long acc[KSTAMP_N]; unsigned long long last; };
+#define KSTAMP_DECL KStamps kst; for (int i_ = 0; i_ < KSTAMP_N; i_++) kst.acc[i_] = 0; kst.last = wall_clock64();
+#define KSTAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = wall_clock64(); kst.acc[i] += t_ - kst.last; kst.last = t_; } while (0)
+#define KSTAMP_ARG , KStamps &kst
+#define KSTAMP_PASS , kst
+#else
+#define KSTAMP_DECL
+#define KSTAMP(i) do { } while (0)
+#define KSTAMP_ARG
+#define KSTAMP_PASS
+#endif
+
 // counting tables: protein id -> (count, lowest matching position)
-template <int LOG2CAP> struct LdsTable {
+template <int LOG2CAP, bool FIRSTPOS = true> struct LdsTable {
     volatile uint32_t *keys;
     uint32_t *cnt, *minpos, *nd;
     static constexpr uint32_t CAP = 1u << LOG2CAP;
@@ -301,7 +332,7 @@ template <int LOG2CAP> struct LdsTable {
             if (k == pid) {
                 if (!(ablate & 8u)) {
                     atomicAdd(&cnt[h], n);
-                    atomicMin(&minpos[h], pos);
+                    if (FIRSTPOS) atomicMin(&minpos[h], pos);
                 }
                 return true;
             }
@@ -374,7 +405,7 @@ __device__ __forceinline__ bool add_runs(const Table &tab, uint32_t x, uint32_t 
 template <class Table, int NWIN, bool COUNT_ONLY>
 __device__ __forceinline__ bool count_windows(const CountParams &p, const uint32_t *vals, const uint4 *heads,
                                               int32_t size, int32_t c0, int32_t stride, const Table &tab, PostCtr &c,
-                                              volatile uint32_t *s_pref)
+                                              volatile uint32_t *s_pref KSTAMP_ARG)
 {
     const uint32_t lane = lane_id();
     uint32_t v[NWIN];
@@ -386,6 +417,7 @@ __device__ __forceinline__ bool count_windows(const CountParams &p, const uint32
         h[k] = make_uint4(0, 0, 0, 0);
         if (pos < size) { v[k] = vals[pos]; h[k] = heads[pos]; }
     }
+    KSTAMP(2);
     bool ok = true;
     uint32_t nnew = 0;
     // leftovers (ids beyond the three that came with the head): all their loads are issued
@@ -449,6 +481,7 @@ __device__ __forceinline__ bool count_windows(const CountParams &p, const uint32
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
+    KSTAMP(3);
     // heads: inline ids and the first three ids of every list
 #pragma unroll
     for (int k = 0; k < NWIN; k++) {
@@ -473,160 +506,11 @@ __device__ __forceinline__ bool count_windows(const CountParams &p, const uint32
         const uint32_t wave_new = wave_total(nnew);
         if (lane == 0 && wave_new) atomicAdd(tab.nd, wave_new);
     }
+    KSTAMP(4);
     return __all(ok);
 }
 
-// ---- S and L tiers: counting table in LDS ---------------------------------------------------------
-//   S: WAVES = 1, one wave per query, items pulled from a queue
-//   L: WAVES = 8, one workgroup per query (long queries, S-tier overflows)
-template <int LOG2CAP, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void count_lds_kernel(CountParams p)
-{
-    constexpr int CAP = 1 << LOG2CAP;
-    constexpr int STRIPES = CAP / 64;
-    static_assert(STRIPES <= 64, "stripe prefix uses one wave");
-    __shared__ uint32_t t_keys[CAP];
-    __shared__ uint32_t t_cnt[CAP];
-    __shared__ uint32_t t_min[CAP];
-    __shared__ uint32_t s_nd, s_ovf;
-    __shared__ uint32_t s_stripe[STRIPES];
-    constexpr int NWIN = (WAVES == 1) ? S_NWIN : 2;  // windows in flight per wave
-    __shared__ uint32_t s_pref[WAVES][NWIN * 64];
-    __shared__ unsigned long long s_base;
-
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    const uint32_t n_items = *p.list_count < p.list_cap ? *p.list_count : p.list_cap;
-
-    LdsTable<LOG2CAP> tab;
-    tab.keys = t_keys; tab.cnt = t_cnt; tab.minpos = t_min; tab.nd = &s_nd; tab.ablate = p.ablate;
-
-    unsigned long long tot_in = 0, tot_q = 0, tot_post = 0, tot_hits = 0, tot_ovf = 0, tot_lists = 0, tot_lids = 0;
-    PostCtr pc;
-    uint64_t chunk_base = 0;
-    uint32_t chunk_left = 0;
-
-    uint32_t item = blockIdx.x;
-    while (item < n_items) {
-        const WorkItem wi = p.list[item];
-        const uint32_t q = wi.q;
-        const int32_t size = wi.size;
-        const uint32_t *vals = p.vals + wi.aa_off;
-        const uint4 *heads = p.heads + wi.aa_off;
-        for (uint32_t i = tid; i < (uint32_t)CAP; i += 64 * WAVES) { t_keys[i] = KH_EMPTY_PID; t_cnt[i] = 0; t_min[i] = 0xFFFFFFFFu; }
-        if (tid == 0) { s_nd = 0; s_ovf = 0; }
-        pc.clear();
-        __syncthreads();
-
-        bool overflow = false;
-        for (int32_t r0 = 0; r0 < size && !overflow; r0 += 64 * WAVES * NWIN) {
-            const bool ok = count_windows<LdsTable<LOG2CAP>, NWIN, false>(p, vals, heads, size, r0 + 64 * (int32_t)wv,
-                                                                         64 * WAVES, tab, pc, s_pref[wv]);
-            if (!ok) s_ovf = 1;
-            __syncthreads();
-            overflow = (*(volatile uint32_t *)&s_ovf != 0u) || tab.over_limit();
-            if (WAVES > 1) __syncthreads();
-        }
-
-        if (overflow) {
-            // hand the query to the next tier; its postings are counted there
-            if (wv == 0) tot_ovf++;
-            if (tid == 0) {
-                const uint32_t slot = atomicAdd(p.ovf_count, 1u);
-                if (slot < p.list_cap) p.ovf_list[slot] = wi;
-                else atomicOr(p.status, (uint32_t)ST_LIST_FULL);
-                p.q_cnt[q] = 0;
-                p.q_start[q] = 0;
-            }
-        } else {
-            tot_post += wave_total(pc.post); tot_lists += wave_total(pc.lists); tot_lids += wave_total(pc.lids);
-            if (wv == 0) { tot_q++; tot_in += (unsigned long long)size + 6; }
-            // ---- compaction: ballot + prefix popcount -> dense hit list in the pool
-            const uint32_t total = (p.ablate & 16u) ? 0u : *(volatile uint32_t *)&s_nd;
-            uint64_t base = 0;
-            bool have = true;
-            if (total > 0) {
-                if (WAVES == 1) {
-                    if (total > chunk_left) {
-                        const uint32_t need = total > POOL_CHUNK ? total : POOL_CHUNK;
-                        const uint32_t shard = blockIdx.x % POOL_SHARDS;
-                        unsigned long long b = 0;
-                        if (lane == 0) b = atomicAdd(&p.pool_cursor[shard * CURSOR_STRIDE], (unsigned long long)need);
-                        b = __shfl(b, 0, 64);
-                        if (b + need > p.pool_shard_cap) {
-                            if (lane == 0) atomicOr(p.status, (uint32_t)ST_POOL_FULL);
-                            have = false;
-                        } else {
-                            chunk_base = (uint64_t)shard * p.pool_shard_cap + b;
-                            chunk_left = need;
-                        }
-                    }
-                    if (have) {
-                        base = chunk_base;
-                        chunk_base += total;
-                        chunk_left -= total;
-                        uint32_t running = 0;
-                        for (uint32_t i0 = 0; i0 < (uint32_t)CAP; i0 += 64) {
-                            const uint32_t k = t_keys[i0 + lane];
-                            const bool has = k != KH_EMPTY_PID;
-                            const unsigned long long bm = __ballot(has);
-                            if (has && !(p.ablate & 4u)) {
-                                const uint32_t idx = running + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull));
-                                p.pool_pid[base + idx] = k;
-                                p.pool_km[base + idx] = t_cnt[i0 + lane];
-                                p.pool_fp[base + idx] = t_min[i0 + lane];
-                            }
-                            running += (uint32_t)__popcll(bm);
-                        }
-                    }
-                } else {
-                    if (tid == 0) {
-                        const uint32_t shard = blockIdx.x % POOL_SHARDS;
-                        const unsigned long long b = atomicAdd(&p.pool_cursor[shard * CURSOR_STRIDE], (unsigned long long)total);
-                        if (b + total > p.pool_shard_cap) { atomicOr(p.status, (uint32_t)ST_POOL_FULL); s_base = ~0ull; }
-                        else s_base = (unsigned long long)shard * p.pool_shard_cap + b;
-                    }
-                    for (uint32_t st = wv; st < (uint32_t)STRIPES; st += WAVES) {
-                        const unsigned long long bm = __ballot(t_keys[st * 64 + lane] != KH_EMPTY_PID);
-                        if (lane == 0) s_stripe[st] = (uint32_t)__popcll(bm);
-                    }
-                    __syncthreads();
-                    base = s_base;
-                    have = base != ~0ull;
-                    if (have) {
-                        for (uint32_t st = wv; st < (uint32_t)STRIPES; st += WAVES) {
-                            const uint32_t before = wave_sum32(lane < st ? s_stripe[lane] : 0u);
-                            const uint32_t k = t_keys[st * 64 + lane];
-                            const bool has = k != KH_EMPTY_PID;
-                            const unsigned long long bm = __ballot(has);
-                            if (has) {
-                                const uint32_t idx = before + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull));
-                                p.pool_pid[base + idx] = k;
-                                p.pool_km[base + idx] = t_cnt[st * 64 + lane];
-                                p.pool_fp[base + idx] = t_min[st * 64 + lane];
-                            }
-                        }
-                    }
-                }
-                if (wv == 0 && have) tot_hits += total;
-            }
-            if (tid == 0) { p.q_cnt[q] = have ? total : 0u; p.q_start[q] = have ? base : 0; }
-        }
-        // static striding: one shared queue word would serialise every wave of the grid
-        // behind the L2 atomic unit (~88 dequeues/us)
-        item += gridDim.x;
-        __syncthreads();
-    }
-    if (lane == 0) {
-        const uint32_t rep = blockIdx.x * WAVES + wv;
-        add_counter(p.counters, rep, CTR_IN, tot_in);
-        add_counter(p.counters, rep, CTR_QUERIES, tot_q);
-        add_counter(p.counters, rep, CTR_POST, tot_post);
-        add_counter(p.counters, rep, CTR_HITS, tot_hits);
-        add_counter(p.counters, rep, CTR_OVERFLOW, tot_ovf);
-        add_counter(p.counters, rep, CTR_LISTS, tot_lists);
-        add_counter(p.counters, rep, CTR_LIST_IDS, tot_lids);
-    }
-}
+#include "count_group.hip.inc"
 
 // ---- G tier: counting table in HBM, sized from the query's exact postings count -------------------
 struct NullTable {
@@ -645,9 +529,10 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint32_t n_items = *p.list_count < p.list_cap ? *p.list_count : p.list_cap;
-    unsigned long long tot_in = 0, tot_q = 0, tot_post = 0, tot_hits = 0, tot_lists = 0, tot_lids = 0;
+    unsigned long long tot_hits = 0;
     PostCtr pc;
     NullTable nt;
+    KSTAMP_DECL
     nt.nd = &s_nd;
 
     for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
@@ -661,7 +546,7 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
         // pass 1: exact number of postings (an upper bound of the distinct proteins)
         pc.clear();
         for (int32_t r0 = 0; r0 < size; r0 += 64 * WAVES * NWIN)
-            count_windows<NullTable, NWIN, true>(p, vals, heads, size, r0 + 64 * (int32_t)wv, 64 * WAVES, nt, pc, s_pref[wv]);
+            count_windows<NullTable, NWIN, true>(p, vals, heads, size, r0 + 64 * (int32_t)wv, 64 * WAVES, nt, pc, s_pref[wv] KSTAMP_PASS);
         {
             const unsigned long long wp = wave_total(pc.post);
             if (lane == 0 && wp) atomicAdd(&s_post, wp);
@@ -693,13 +578,12 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
         pc.clear();
         for (int32_t r0 = 0; r0 < size; r0 += 64 * WAVES * NWIN) {
             const bool ok = count_windows<GlobalTable, NWIN, false>(p, vals, heads, size, r0 + 64 * (int32_t)wv, 64 * WAVES, gt,
-                                                                   pc, s_pref[wv]);
+                                                                   pc, s_pref[wv] KSTAMP_PASS);
             if (!ok) s_fail = 1;
         }
         __threadfence();
         __syncthreads();
-        tot_post += wave_total(pc.post); tot_lists += wave_total(pc.lists); tot_lids += wave_total(pc.lids);
-        if (wv == 0) { tot_q++; tot_in += (unsigned long long)size + 6; }
+        // lookups, postings and queries were already counted by the group kernel
         const uint32_t total = s_nd;
         const bool failed = s_fail != 0;
         if (tid == 0) {
@@ -736,12 +620,7 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
     }
     if (lane == 0) {
         const uint32_t rep = blockIdx.x * WAVES + wv;
-        add_counter(p.counters, rep, CTR_IN, tot_in);
-        add_counter(p.counters, rep, CTR_QUERIES, tot_q);
-        add_counter(p.counters, rep, CTR_POST, tot_post);
         add_counter(p.counters, rep, CTR_HITS, tot_hits);
-        add_counter(p.counters, rep, CTR_LISTS, tot_lists);
-        add_counter(p.counters, rep, CTR_LIST_IDS, tot_lids);
     }
 }
 
@@ -762,10 +641,10 @@ __device__ __forceinline__ void mark_invalid_range(unsigned long long *invalid, 
     }
 }
 
-__global__ void prep_protein_kernel(const uint8_t *seqs, const uint64_t *offsets, uint32_t n_seqs, int32_t s_max_size,
+__global__ void prep_protein_kernel(const uint8_t *seqs, const uint64_t *offsets, uint32_t n_seqs,
                                     kaamer_query_meta *q, uint32_t *d_nq, unsigned long long *d_n_pos,
-                                    unsigned long long *invalid, WorkItem *lists, uint32_t *list_counts,
-                                    uint32_t list_cap, uint64_t *q_start, uint32_t *q_cnt)
+                                    unsigned long long *invalid, QInfo *qinfo, uint32_t *slots, uint64_t *q_start,
+                                    uint32_t *q_cnt)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
@@ -774,48 +653,36 @@ __global__ void prep_protein_kernel(const uint8_t *seqs, const uint64_t *offsets
         *d_n_pos = n_pos;
         mark_invalid_range(invalid, n_pos, (n_pos + 63) & ~63ull);  // bits past the end, in the last word P reads
     }
-    int which = -1;
-    WorkItem wi;
-    wi.q = i; wi.size = 0; wi.aa_off = 0;
-    if (i < n_seqs) {
-        const uint64_t b = offsets[i], e = offsets[i + 1];
-        const int64_t len = (int64_t)(e - b);
-        int32_t size = (int32_t)(len - KAAMER_KMER_SIZE + 1);       // search.go:290
-        if (len > 0 && seqs[e - 1] == '*') size--;                  // search.go:291-293
-        kaamer_query_meta m;
-        m.src_seq = i;
-        m.size_in_kmer = size;
-        m.start_position = 1;                                       // search.go:225,303
-        m.end_position = (int32_t)len;                              // search.go:294
-        m.plus_strand = 1;
-        m.aa_len = (uint32_t)len;
-        m.aa_off = b;
-        m.sa_off = 0;
-        m.sa_len = 0;
-        q[i] = m;
-        q_cnt[i] = 0;
-        q_start[i] = 0;
-        wi.size = size;
-        wi.aa_off = b;
-        if (size >= 7) {                                            // search_protein.go:74-76
-            which = size <= s_max_size ? LIST_S : LIST_L;
-            mark_invalid_range(invalid, b + (uint64_t)size, e);      // positions >= SizeInKmer start no k-mer
-        } else {
-            mark_invalid_range(invalid, b, e);                       // the whole query is dropped
-        }
+    if (i >= n_seqs) return;
+    const uint64_t b = offsets[i], e = offsets[i + 1];
+    const int64_t len = (int64_t)(e - b);
+    int32_t size = (int32_t)(len - KAAMER_KMER_SIZE + 1);       // search.go:290
+    if (len > 0 && seqs[e - 1] == '*') size--;                  // search.go:291-293
+    kaamer_query_meta m;
+    m.src_seq = i;
+    m.size_in_kmer = size;
+    m.start_position = 1;                                       // search.go:225,303
+    m.end_position = (int32_t)len;                              // search.go:294
+    m.plus_strand = 1;
+    m.aa_len = (uint32_t)len;
+    m.aa_off = b;
+    m.sa_off = 0;
+    m.sa_len = 0;
+    q[i] = m;
+    q_cnt[i] = 0;
+    q_start[i] = 0;
+    QInfo qi;
+    qi.size = size;
+    qi.aa_off = b;
+    if (size >= 7) {                                            // search_protein.go:74-76
+        qi.slots = table_slots_for(size);
+        mark_invalid_range(invalid, b + (uint64_t)size, e);      // positions >= SizeInKmer start no k-mer
+    } else {
+        qi.slots = 0;
+        mark_invalid_range(invalid, b, e);                       // the whole query is dropped
     }
-    // wave-aggregated append to the tier lists
-#pragma unroll
-    for (int l = LIST_S; l <= LIST_L; l++) {
-        const unsigned long long m = __ballot(which == l);
-        if (m) {
-            uint32_t base = 0;
-            const uint32_t lane = threadIdx.x & 63u;
-            if (lane == (uint32_t)(__ffsll((long long)m) - 1)) base = atomicAdd(&list_counts[l], (uint32_t)__popcll(m));
-            base = __shfl(base, __ffsll((long long)m) - 1, 64);
-            if (which == l) lists[(size_t)l * list_cap + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = wi;
-        }
-    }
+    qinfo[i] = qi;
+    slots[i] = qi.slots;
 }
 
 #include "translate.hip.inc"
@@ -984,9 +851,7 @@ struct kaamer_workspace {
     kaamer_workspace_opts opts;
     uint32_t q_cap;
     uint64_t hit_cap, pool_cap, g_slots, pos_cap;
-    uint32_t s_log2;
-    int32_t s_max_size;
-    int s_grid, l_grid, g_grid, p_grid, n_cu;
+    int g_grid, p_grid, n_cu;
     // device buffers
     kaamer_query_meta *d_q;
     uint32_t *d_nq;
@@ -997,7 +862,14 @@ struct kaamer_workspace {
     uint32_t *d_q_cnt;
     uint32_t *d_pool_pid, *d_pool_km, *d_pool_fp;
     unsigned long long *d_pool_cursor;  // POOL_SHARDS pool cursors + the G arena cursor, CURSOR_STRIDE apart
-    WorkItem *d_lists;                  // [N_LISTS][q_cap]
+    WorkItem *d_lists;                  // [N_LISTS][q_cap] (only the G tier's overflow list is used)
+    QInfo *d_qinfo;
+    uint32_t *d_slots;
+    uint64_t *d_slot_off;
+    uint32_t *d_group_first;
+    uint32_t *d_n_groups;
+    uint32_t groups_cap;
+    int grp_grid;
     uint4 *d_heads;                     // postings heads per residue position
     // nucleotide / reads input: 6-frame translation products
     bool nucleotide;
@@ -1014,10 +886,12 @@ struct kaamer_workspace {
     uint32_t *d_list_counts;            // [N_LISTS] + queue head + status (zeroed by finalize)
     uint32_t *d_status_out;             // status of the last finished batch
     bool clean;                         // per-batch device state is known to be zeroed
+    bool firstpos;                      // track the lowest matching position per hit
+    unsigned long long *d_stamps;       // diagnostic build only
     uint32_t *d_g_keys, *d_g_cnt, *d_g_min;
     unsigned long long *d_counter_replicas;
     kaamer_counters *d_counters;
-    uint64_t *d_bsum;
+    uint64_t *d_bsum, *d_bsum2;
     uint32_t n_scan_blocks;
     uint64_t *d_hit_off;
     uint32_t *d_hit_pid, *d_hit_km, *d_hit_fp;
@@ -1036,14 +910,10 @@ template <class T> static int dev_alloc(T **p, size_t n)
     return KAAMER_OK;
 }
 
-template <int L> static void launch_s(const CountParams &p, int grid, hipStream_t s)
+static void launch_group(const CountParams &p, int grid, bool firstpos, hipStream_t s)
 {
-    hipLaunchKernelGGL((count_lds_kernel<L, 1>), dim3(grid), dim3(64), 0, s, p);
-}
-template <int L> static int s_occupancy(int *blocks_per_cu)
-{
-    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, count_lds_kernel<L, 1>, 64, 0));
-    return KAAMER_OK;
+    if (firstpos) hipLaunchKernelGGL(count_group_kernel<true>, dim3(grid), dim3(64 * GRP_WAVES), 0, s, p);
+    else hipLaunchKernelGGL(count_group_kernel<false>, dim3(grid), dim3(64 * GRP_WAVES), 0, s, p);
 }
 
 extern "C" {
@@ -1104,8 +974,9 @@ void kaamer_workspace_free(kaamer_workspace *ws)
     (void)hipSetDevice(ws->device);
     void *bufs[] = { ws->d_q, ws->d_nq, ws->d_n_pos, ws->d_valid, ws->d_vals, ws->d_heads, ws->d_cnt3, ws->d_off3, ws->d_n6,
                      ws->d_tmp_meta, ws->d_orf_aa, ws->d_starts_alt, ws->d_q_start, ws->d_q_cnt, ws->d_pool_pid,
-                     ws->d_pool_km, ws->d_pool_fp, ws->d_pool_cursor, ws->d_lists, ws->d_list_counts, ws->d_status_out, ws->d_g_keys,
-                     ws->d_g_cnt, ws->d_g_min, ws->d_counter_replicas, ws->d_counters, ws->d_bsum, ws->d_hit_off,
+                     ws->d_pool_km, ws->d_pool_fp, ws->d_pool_cursor, ws->d_lists, ws->d_list_counts, ws->d_status_out, ws->d_stamps, ws->d_qinfo, ws->d_slots,
+                     ws->d_slot_off, ws->d_group_first, ws->d_n_groups, ws->d_g_keys,
+                     ws->d_g_cnt, ws->d_g_min, ws->d_counter_replicas, ws->d_counters, ws->d_bsum, ws->d_bsum2, ws->d_hit_off,
                      ws->d_hit_pid, ws->d_hit_km, ws->d_hit_fp };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (ws->ev) {
@@ -1144,41 +1015,32 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     }
     if (ws->q_cap < 1) ws->q_cap = 1;
     ws->hit_cap = opts->max_hits ? opts->max_hits : (uint64_t)ws->q_cap * 256 + (1u << 20);
-    const uint32_t slots = opts->lds_slots ? opts->lds_slots : 512;
-    uint32_t l2 = 6;
-    while ((1u << l2) < slots && l2 < 11) l2++;
-    if ((1u << l2) != slots) { delete ws; return kaamer_fail(KAAMER_E_ARG, "lds_slots must be a power of two in [64,2048]"); }
-    ws->s_log2 = l2;
-    ws->s_max_size = opts->s_tier_max_kmers ? (int32_t)opts->s_tier_max_kmers : 384;
-    if (const char *e = getenv("KAAMER_S_MAX_KMERS")) ws->s_max_size = atoi(e);
     ws->g_slots = opts->g_tier_slots ? opts->g_tier_slots : (32ull << 20);
-    int per_cu = 0, l_per_cu = 0, p_per_cu = 0, rc = KAAMER_OK;
-    switch (l2) {
-    case 6: rc = s_occupancy<6>(&per_cu); break;
-    case 7: rc = s_occupancy<7>(&per_cu); break;
-    case 8: rc = s_occupancy<8>(&per_cu); break;
-    case 9: rc = s_occupancy<9>(&per_cu); break;
-    case 10: rc = s_occupancy<10>(&per_cu); break;
-    default: rc = s_occupancy<11>(&per_cu); break;
-    }
-    if (rc) { delete ws; return rc; }
-    hipError_t oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&l_per_cu, count_lds_kernel<L_LOG2CAP, L_WAVES>, 64 * L_WAVES, 0);
+    // the reference fills PositionHits only for nucleotide/reads input or with -pos (search.go:416)
+    ws->firstpos = opts->first_pos == 1 || (opts->first_pos == 0 && (opts->seq_type == KAAMER_NUCLEOTIDE || opts->seq_type == KAAMER_READS));
+    int grp_per_cu = 0, p_per_cu = 0;
+    hipError_t oe = ws->firstpos
+        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&grp_per_cu, count_group_kernel<true>, 64 * GRP_WAVES, 0)
+        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&grp_per_cu, count_group_kernel<false>, 64 * GRP_WAVES, 0);
     if (oe == hipSuccess) oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&p_per_cu, probe_kernel, 64 * P_WAVES, 0);
     if (oe != hipSuccess) { delete ws; return kaamer_fail(KAAMER_E_HIP, "occupancy query: %s", hipGetErrorString(oe)); }
     hipDeviceProp_t prop;
     hipError_t pe = hipGetDeviceProperties(&prop, ix->device);
     if (pe != hipSuccess) { delete ws; return kaamer_fail(KAAMER_E_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(pe)); }
-    if (per_cu < 1) per_cu = 1;
-    if (per_cu > 32) per_cu = 32;
-    if (l_per_cu < 1) l_per_cu = 1;
+    if (grp_per_cu < 1) grp_per_cu = 1;
     if (p_per_cu < 1) p_per_cu = 1;
     ws->n_cu = prop.multiProcessorCount;
-    ws->s_grid = ws->n_cu * per_cu;
-    ws->l_grid = ws->n_cu * l_per_cu;
+    ws->grp_grid = ws->n_cu * grp_per_cu;
     ws->g_grid = ws->n_cu * 2;
     ws->p_grid = ws->n_cu * p_per_cu;
-    // every resident S wave may hold one partly used chunk; shards fill unevenly (+25 %)
-    ws->pool_cap = ws->hit_cap + ws->hit_cap / 4 + (uint64_t)ws->s_grid * POOL_CHUNK + POOL_SHARDS * 4096ull;
+    // a table has at most max(64, 3 x SizeInKmer) slots
+    {
+        const uint64_t gc = ((uint64_t)GRP_MIN_TABLE * ws->q_cap + 3 * ws->pos_cap) / GRP_BUDGET + 4;
+        ws->groups_cap = (uint32_t)(gc > 0x7FFFFFFFull ? 0x7FFFFFFFull : gc);
+    }
+    int rc = KAAMER_OK;
+    // reservations are exact (one per query group); the 64 shard regions fill unevenly (+50 %)
+    ws->pool_cap = ws->hit_cap + ws->hit_cap / 2 + POOL_SHARDS * 8192ull;
     ws->pool_cap = (ws->pool_cap + POOL_SHARDS - 1) / POOL_SHARDS * POOL_SHARDS;
     {
         uint64_t n = ws->q_cap;
@@ -1209,12 +1071,22 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     if (!rc) rc = dev_alloc(&ws->d_lists, (size_t)N_LISTS * ws->q_cap);
     if (!rc) rc = dev_alloc(&ws->d_list_counts, N_SMALL_SLOTS);
     if (!rc) rc = dev_alloc(&ws->d_status_out, 1);
+    if (!rc) rc = dev_alloc(&ws->d_qinfo, ws->q_cap);
+    if (!rc) rc = dev_alloc(&ws->d_slots, ws->q_cap);
+    if (!rc) rc = dev_alloc(&ws->d_slot_off, (size_t)ws->q_cap + 1);
+    if (!rc) rc = dev_alloc(&ws->d_group_first, ws->groups_cap);
+    if (!rc) rc = dev_alloc(&ws->d_n_groups, 1);
+#ifdef KAAMER_STAMPS
+    if (!rc) rc = dev_alloc(&ws->d_stamps, 64);
+    if (!rc) (void)hipMemset(ws->d_stamps, 0, 64 * sizeof(unsigned long long));
+#endif
     if (!rc) rc = dev_alloc(&ws->d_g_keys, ws->g_slots);
     if (!rc) rc = dev_alloc(&ws->d_g_cnt, ws->g_slots);
     if (!rc) rc = dev_alloc(&ws->d_g_min, ws->g_slots);
     if (!rc) rc = dev_alloc(&ws->d_counter_replicas, (size_t)CTR_REPLICAS * CTR_N);
     if (!rc) rc = dev_alloc(&ws->d_counters, 1);
     if (!rc) rc = dev_alloc(&ws->d_bsum, ws->n_scan_blocks);
+    if (!rc) rc = dev_alloc(&ws->d_bsum2, ws->n_scan_blocks);
     if (!rc) rc = dev_alloc(&ws->d_hit_off, (size_t)ws->q_cap + 1);
     if (!rc) rc = dev_alloc(&ws->d_hit_pid, ws->hit_cap);
     if (!rc) rc = dev_alloc(&ws->d_hit_km, ws->hit_cap);
@@ -1259,6 +1131,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         HIPCHK(hipMemsetAsync(ws->d_list_counts, 0, N_SMALL_SLOTS * sizeof(uint32_t), s));
         HIPCHK(hipMemsetAsync(ws->d_counter_replicas, 0, sizeof(unsigned long long) * CTR_REPLICAS * CTR_N, s));
         HIPCHK(hipMemsetAsync(ws->d_valid, 0, (size_t)(ws->pos_cap / 64 + 2) * sizeof(unsigned long long), s));
+        HIPCHK(hipMemsetAsync(ws->d_group_first, 0xFF, (size_t)ws->groups_cap * sizeof(uint32_t), s));
     }
     ws->clean = false;
 
@@ -1270,8 +1143,8 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     uint32_t nq_bound = n_seqs;         // host-side bound of the number of queries
     if (!nucl) {
         hipLaunchKernelGGL(prep_protein_kernel, dim3((n_seqs + pb - 1) / pb > 0 ? (n_seqs + pb - 1) / pb : 1), dim3(pb), 0, s,
-                           d_seqs, d_offsets, n_seqs, ws->s_max_size, ws->d_q, ws->d_nq, ws->d_n_pos, ws->d_valid,
-                           ws->d_lists, ws->d_list_counts, ws->q_cap, ws->d_q_start, ws->d_q_cnt);
+                           d_seqs, d_offsets, n_seqs, ws->d_q, ws->d_nq, ws->d_n_pos, ws->d_valid, ws->d_qinfo, ws->d_slots,
+                           ws->d_q_start, ws->d_q_cnt);
     } else {
         // 6-frame translation: count, scan, write, order (translate.hip.inc)
         const size_t n6 = (size_t)n_seqs * 6, cap6 = (size_t)ws->max_seqs * 6;
@@ -1301,12 +1174,33 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         hipLaunchKernelGGL(translate_kernel<true>, dim3(tgrid), dim3(64), 0, s, tp);
         hipLaunchKernelGGL(orf_order_kernel, dim3(ws->n_cu * 4), dim3(256), 0, s, ws->d_tmp_meta, tp.off_orf, n_seqs, ws->d_q,
                            ws->d_nq, ws->d_n_pos, tp.off_aa, (uint64_t)ws->q_cap, status);
-        hipLaunchKernelGGL(prep_orf_kernel, dim3(ws->n_cu * 4), dim3(pb), 0, s, ws->d_q, ws->d_nq, ws->s_max_size, ws->d_valid,
-                           ws->d_n_pos, ws->d_lists, ws->d_list_counts, ws->q_cap, ws->d_q_start, ws->d_q_cnt);
+        hipLaunchKernelGGL(prep_orf_kernel, dim3(ws->n_cu * 4), dim3(pb), 0, s, ws->d_q, ws->d_nq, ws->d_valid, ws->d_n_pos,
+                           ws->d_qinfo, ws->d_slots, ws->d_q_start, ws->d_q_cnt);
         residues = ws->d_orf_aa;
         pos_bound = ws->aa_cap;
         nq_bound = ws->q_cap;
     }
+
+    // ---- query groups: scan of the table capacities + first query of each group, on the side
+    // stream beside kernels P and H (they only share prep's outputs)
+    HIPCHK(hipEventRecord(ws->ev_fork, s));
+    HIPCHK(hipStreamWaitEvent(ws->side, ws->ev_fork, 0));
+    if (nq_bound <= 8 * SCAN_TILE) {
+        hipLaunchKernelGGL(scan_single_kernel, dim3(1), dim3(SCAN_BLOCK), 0, ws->side, ws->d_slots, ws->d_nq, ws->d_slot_off);
+    } else {
+        const uint32_t nsb = (uint32_t)(((uint64_t)nq_bound + 1 + SCAN_TILE - 1) / SCAN_TILE);
+        hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nsb), dim3(SCAN_BLOCK), 0, ws->side, ws->d_slots, ws->d_nq, ws->d_bsum2);
+        hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_BLOCK), 0, ws->side, ws->d_bsum2, nsb);
+        hipLaunchKernelGGL(scan_apply_kernel, dim3(nsb), dim3(SCAN_BLOCK), 0, ws->side, ws->d_slots, ws->d_nq, ws->d_bsum2, ws->d_slot_off);
+    }
+    {
+        uint32_t gb = (nq_bound + 255) / 256;
+        if (gb < 1) gb = 1;
+        if (gb > (uint32_t)ws->n_cu * 8) gb = (uint32_t)ws->n_cu * 8;
+        hipLaunchKernelGGL(group_build_kernel, dim3(gb), dim3(256), 0, ws->side, ws->d_qinfo, ws->d_slot_off, ws->d_nq,
+                           ws->d_group_first, ws->d_n_groups, ws->groups_cap, status);
+    }
+    HIPCHK(hipEventRecord(ws->ev_join, ws->side));
 
     // ---- kernel P: flat probe
     ProbeParams pp;
@@ -1332,12 +1226,17 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         hipLaunchKernelGGL(heads_kernel, dim3((unsigned)hb), dim3(256), 0, s, ws->d_vals, ix->d_arena, ws->d_n_pos, ws->d_heads);
     }
 
-    // ---- kernel C: counting tiers
+    // ---- kernel C: counting
     CountParams p;
     memset(&p, 0, sizeof p);
     p.arena = ix->d_arena;
     p.vals = ws->d_vals;
     p.heads = ws->d_heads;
+    p.qinfo = ws->d_qinfo;
+    p.slot_off = ws->d_slot_off;
+    p.group_first = ws->d_group_first;
+    p.d_n_groups = ws->d_n_groups;
+    p.d_nq = ws->d_nq;
     p.list_cap = ws->q_cap;
     p.queue_head = queue_head;
     p.q_start = ws->d_q_start;
@@ -1355,35 +1254,19 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     p.n_proteins = ix->hdr.max_protein_id + 1u ? ix->hdr.max_protein_id + 1u : 0xFFFFFFFFu;
     p.counters = ws->d_counter_replicas;
     p.status = status;
+    p.stamps = ws->d_stamps;
     if (const char *e = getenv("KAAMER_ABLATE")) p.ablate = (uint32_t)atoi(e);
     auto list_ptr = [&](int which) { return ws->d_lists + (size_t)which * ws->q_cap; };
 
-    // the L tier (long queries) runs on the side stream beside the S tier: both are
-    // latency-bound and leave most of the chip idle when run alone
-    int l_grid = ws->l_grid;
-    if ((uint32_t)l_grid > nq_bound) l_grid = nq_bound > 0 ? (int)nq_bound : 1;
-    CountParams pl = p;
-    pl.list = list_ptr(LIST_L); pl.list_count = ws->d_list_counts + LIST_L;
-    pl.ovf_list = list_ptr(LIST_G); pl.ovf_count = ws->d_list_counts + LIST_G;
-    HIPCHK(hipEventRecord(ws->ev_fork, s));
-    HIPCHK(hipStreamWaitEvent(ws->side, ws->ev_fork, 0));
-    hipLaunchKernelGGL((count_lds_kernel<L_LOG2CAP, L_WAVES>), dim3(l_grid), dim3(64 * L_WAVES), 0, ws->side, pl);
-    HIPCHK(hipEventRecord(ws->ev_join, ws->side));
-
-    int s_grid = ws->s_grid;
-    if ((uint32_t)s_grid > nq_bound) s_grid = nq_bound > 0 ? (int)nq_bound : 1;
-    CountParams ps = p;
-    ps.list = list_ptr(LIST_S); ps.list_count = ws->d_list_counts + LIST_S;
-    ps.ovf_list = list_ptr(LIST_G); ps.ovf_count = ws->d_list_counts + LIST_G;
-    switch (ws->s_log2) {
-    case 6: launch_s<6>(ps, s_grid, s); break;
-    case 7: launch_s<7>(ps, s_grid, s); break;
-    case 8: launch_s<8>(ps, s_grid, s); break;
-    case 9: launch_s<9>(ps, s_grid, s); break;
-    case 10: launch_s<10>(ps, s_grid, s); break;
-    default: launch_s<11>(ps, s_grid, s); break;
-    }
     HIPCHK(hipStreamWaitEvent(s, ws->ev_join, 0));
+    CountParams pc = p;
+    pc.ovf_list = list_ptr(LIST_G); pc.ovf_count = ws->d_list_counts + LIST_G;
+    {
+        // at most one workgroup per group; groups <= slots / GRP_BUDGET
+        uint64_t gb = ((uint64_t)GRP_MIN_TABLE * nq_bound + 3 * pos_bound) / GRP_BUDGET + 1;
+        if (gb > (uint64_t)ws->grp_grid) gb = ws->grp_grid;
+        launch_group(pc, (int)gb, ws->firstpos, s);
+    }
     CountParams pg = p;
     pg.list = list_ptr(LIST_G); pg.list_count = ws->d_list_counts + LIST_G;
     int g_grid = ws->g_grid;
@@ -1438,6 +1321,22 @@ int kaamer_workspace_finish(kaamer_workspace *ws, void *stream, kaamer_counters 
     kaamer_counters c;
     HIPCHK(hipMemcpy(&c, ws->d_counters, sizeof c, hipMemcpyDeviceToHost));
     if (out) *out = c;
+#ifdef KAAMER_STAMPS
+    {
+        unsigned long long st[64];
+        HIPCHK(hipMemcpy(st, ws->d_stamps, sizeof st, hipMemcpyDeviceToHost));
+        static const char *names[KSTAMP_N] = { "desc", "clear", "load v/h", "leftovers", "adds", "barrier", "compact", "next", "-", "loop" };
+        for (int t = 0; t < 2; t++) {
+            unsigned long long tot = 0;
+            for (int i = 0; i < KSTAMP_N; i++) tot += st[t * KSTAMP_N + i];
+            fprintf(stderr, "[stamps] %s tier (100 MHz ticks summed over workgroups, all batches):", t ? "L" : "S");
+            for (int i = 0; i < KSTAMP_N; i++)
+                if (st[t * KSTAMP_N + i]) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * (double)st[t * KSTAMP_N + i] / (double)(tot ? tot : 1));
+            fprintf(stderr, "  total %llu\n", tot);
+        }
+    }
+#endif
+    if (status) ws->clean = false;  // an aborted batch may leave per-batch state behind
     if (status & ST_POOL_FULL) return kaamer_fail(KAAMER_E_CAPACITY, "hit pool exhausted: raise workspace max_hits (now %llu)", (unsigned long long)ws->hit_cap);
     if (status & ST_LIST_FULL) return kaamer_fail(KAAMER_E_CAPACITY, "tier work list exhausted");
     if (status & (ST_QUERY_CAP | ST_AA_CAP))
@@ -1499,6 +1398,7 @@ static int search_batch_once(kaamer_index *ix, const kaamer_batch_in *in, uint64
     o.max_hits = max_hits;
     o.g_tier_slots = g_slots;
     o.seq_type = in->seq_type;
+    o.first_pos = 1;  // kaamer_batch_out always carries hit_first_pos
     o.max_queries = max_queries;
     kaamer_workspace *ws = nullptr;
     int rc = kaamer_workspace_create(ix, &o, &ws);
