@@ -1155,10 +1155,10 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         tp.off_orf = ws->d_off3; tp.off_aa = ws->d_off3 + (cap6 + 1); tp.off_sa = ws->d_off3 + 2 * (cap6 + 1);
         tp.tmp_meta = ws->d_tmp_meta; tp.orf_aa = ws->d_orf_aa; tp.starts_alt = ws->d_starts_alt;
         tp.q_cap = ws->q_cap; tp.aa_cap = ws->aa_cap; tp.sa_cap = ws->sa_cap; tp.status = status;
-        int tgrid = ws->n_cu * 16;
-        if ((uint32_t)tgrid > n_seqs) tgrid = n_seqs > 0 ? (int)n_seqs : 1;
+        int tgrid = ws->n_cu * 8;  // 256-thread blocks, one (sequence, frame) item per wave at a time
+        if ((uint64_t)tgrid * 4 > n6) tgrid = n6 > 0 ? (int)((n6 + 3) / 4) : 1;
         tp.d_n6 = ws->d_n6;
-        hipLaunchKernelGGL(translate_kernel<false>, dim3(tgrid), dim3(64), 0, s, tp);
+        hipLaunchKernelGGL(translate_kernel<false>, dim3(tgrid), dim3(256), 0, s, tp);
         const uint32_t nsb6 = (uint32_t)((n6 + 1 + SCAN_TILE - 1) / SCAN_TILE);
         for (int a = 0; a < 3; a++) {
             const uint32_t *cnt = ws->d_cnt3 + a * cap6;
@@ -1171,7 +1171,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
                 hipLaunchKernelGGL(scan_apply_kernel, dim3(nsb6), dim3(SCAN_BLOCK), 0, s, cnt, ws->d_n6, ws->d_bsum, off);
             }
         }
-        hipLaunchKernelGGL(translate_kernel<true>, dim3(tgrid), dim3(64), 0, s, tp);
+        hipLaunchKernelGGL(translate_kernel<true>, dim3(tgrid), dim3(256), 0, s, tp);
         hipLaunchKernelGGL(orf_order_kernel, dim3(ws->n_cu * 4), dim3(256), 0, s, ws->d_tmp_meta, tp.off_orf, n_seqs, ws->d_q,
                            ws->d_nq, ws->d_n_pos, tp.off_aa, (uint64_t)ws->q_cap, status);
         hipLaunchKernelGGL(prep_orf_kernel, dim3(ws->n_cu * 4), dim3(pb), 0, s, ws->d_q, ws->d_nq, ws->d_valid, ws->d_n_pos,
