@@ -200,6 +200,9 @@ typedef struct {
     uint32_t first_pos;      /* hit_first_pos: 0 = as the reference fills      */
                              /* PositionHits (nucleotide/reads only,           */
                              /* search.go:416), 1 = always, 2 = never (zeros)  */
+    uint32_t want_positions; /* full PositionHits bitmaps (ExtractPositions)   */
+    uint32_t reserved;
+    uint64_t max_pos_words;  /* u64 words of bitmap storage; 0 = 8 x max_hits  */
 } kaamer_workspace_opts;
 
 typedef struct {
@@ -213,6 +216,9 @@ typedef struct {
     const uint8_t *d_orf_aa;
     const int32_t *d_starts_alt;
     const kaamer_counters *d_counters;  /* device copy, valid after the stream */
+    const uint64_t *d_pos_off;          /* per hit: first word of its bitmap   */
+    const uint64_t *d_pos_bits;         /* NULL unless want_positions          */
+    const uint64_t *d_pos_base;         /* per query: first word; [n] = total  */
 } kaamer_device_result;
 
 int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,

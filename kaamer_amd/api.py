@@ -109,10 +109,30 @@ class BatchResult:
         self.hit_kmatch = np.ctypeslib.as_array(o.hit_kmatch, shape=(nh,)).copy() if nh else z
         self.hit_first_pos = np.ctypeslib.as_array(o.hit_first_pos, shape=(nh,)).copy() if nh else z
         self.counters = o.counters.as_dict()
+        self.pos_off = self.pos_bits = None
+        if bool(o.pos_off) and bool(o.pos_bits):
+            self.pos_off = np.ctypeslib.as_array(o.pos_off, shape=(nh,)).copy() if nh else np.zeros(0, np.uint64)
+            nw = 0
+            if nh:
+                last_q = int(np.searchsorted(self.hit_off, nh - 1, side="right")) - 1
+                nw = int(self.pos_off[nh - 1]) + (int(self.meta["size_in_kmer"][last_q]) + 63) // 64
+            self.pos_bits = np.ctypeslib.as_array(o.pos_bits, shape=(nw,)).copy() if nw else np.zeros(0, np.uint64)
         aa_len = int((self.meta["aa_off"] + self.meta["aa_len"]).max()) if n and bool(o.orf_aa) else 0
         self.orf_aa = np.ctypeslib.as_array(o.orf_aa, shape=(aa_len,)).copy() if aa_len else np.zeros(0, np.uint8)
         sa_len = int((self.meta["sa_off"] + self.meta["sa_len"]).max()) if n and bool(o.starts_alt) else 0
         self.starts_alt = np.ctypeslib.as_array(o.starts_alt, shape=(sa_len,)).copy() if sa_len else np.zeros(0, np.int32)
+
+    def positions(self, q):
+        """{protein id: bool[SizeInKmer]} of query q (PositionHits, search.go:442-452)."""
+        a, b = int(self.hit_off[q]), int(self.hit_off[q + 1])
+        size = int(self.meta["size_in_kmer"][q])
+        out = {}
+        words = (size + 63) // 64
+        for i in range(a, b):
+            w = self.pos_bits[int(self.pos_off[i]):int(self.pos_off[i]) + words]
+            bits = np.unpackbits(w.view(np.uint8), bitorder="little")[:size].astype(bool)
+            out[int(self.hit_pid[i])] = bits
+        return out
 
     def hits(self, q):
         """{protein id: Kmatch} of query q (the parity object: SURVEY §2.1)."""
@@ -178,11 +198,12 @@ class Workspace:
     """Reusable device buffers for the device-resident call."""
 
     def __init__(self, index, max_seq_bytes, max_seqs, max_queries=0, max_hits=0, lds_slots=0,
-                 s_tier_max_kmers=0, g_tier_slots=0, seq_type=abi.PROTEIN, first_pos=0):
+                 s_tier_max_kmers=0, g_tier_slots=0, seq_type=abi.PROTEIN, first_pos=0, want_positions=False,
+                 max_pos_words=0):
         self.index = index
         self.seq_type = seq_type
         o = abi.WorkspaceOpts(max_seq_bytes, max_seqs, max_queries, max_hits, lds_slots, s_tier_max_kmers,
-                              g_tier_slots, seq_type, first_pos)
+                              g_tier_slots, seq_type, first_pos, int(want_positions), 0, max_pos_words)
         h = C.c_void_p()
         abi.check(abi.lib().kaamer_workspace_create(index._h, C.byref(o), C.byref(h)))
         self._h = h

@@ -63,7 +63,8 @@ struct kaamer_index {
     uint32_t *d_arena;
 };
 
-enum { ST_POOL_FULL = 1u, ST_LIST_FULL = 2u, ST_QUERY_CAP = 4u, ST_AA_CAP = 8u, ST_G_ARENA_FULL = 16u, ST_G_TABLE_FULL = 32u };
+enum { ST_POOL_FULL = 1u, ST_LIST_FULL = 2u, ST_QUERY_CAP = 4u, ST_AA_CAP = 8u, ST_G_ARENA_FULL = 16u, ST_G_TABLE_FULL = 32u,
+       ST_POS_UNSUPPORTED = 64u, ST_POS_CAP = 128u };
 enum { CTR_IN = 0, CTR_QUERIES, CTR_LOOKUP, CTR_PROBE, CTR_FOUND, CTR_POST, CTR_HITS, CTR_OVERFLOW, CTR_LISTS, CTR_LIST_IDS, CTR_N };
 static_assert(sizeof(kaamer_counters) == CTR_N * 8, "counter layout");
 #define CTR_REPLICAS 64
@@ -266,6 +267,12 @@ struct CountParams {
     uint32_t *group_first;      // first query of each group (self-cleaning)
     const uint32_t *d_n_groups;
     const uint32_t *d_nq;
+    uint32_t last_group_pass;   // this launch may clear group_first behind itself
+    // PositionHits pass (count_group_kernel MODE 1)
+    const uint64_t *hit_off;
+    const uint32_t *hit_pid;
+    const uint64_t *pos_base;
+    unsigned long long *pos_bits;
     // tier input / overflow output lists
     const WorkItem *list;
     const uint32_t *list_count;
@@ -887,6 +894,12 @@ struct kaamer_workspace {
     uint32_t *d_status_out;             // status of the last finished batch
     bool clean;                         // per-batch device state is known to be zeroed
     bool firstpos;                      // track the lowest matching position per hit
+    bool want_positions;                // full PositionHits bitmaps
+    uint64_t bits_cap;                  // u64 words of bitmap storage
+    uint32_t *d_pos_words;              // per query: hits x words per hit
+    uint64_t *d_pos_base;               // exclusive scan of the above
+    uint64_t *d_pos_off;                // per hit: first word of its bitmap
+    unsigned long long *d_pos_bits;
     unsigned long long *d_stamps;       // diagnostic build only
     uint32_t *d_g_keys, *d_g_cnt, *d_g_min;
     unsigned long long *d_counter_replicas;
@@ -912,8 +925,12 @@ template <class T> static int dev_alloc(T **p, size_t n)
 
 static void launch_group(const CountParams &p, int grid, bool firstpos, hipStream_t s)
 {
-    if (firstpos) hipLaunchKernelGGL(count_group_kernel<true>, dim3(grid), dim3(64 * GRP_WAVES), 0, s, p);
-    else hipLaunchKernelGGL(count_group_kernel<false>, dim3(grid), dim3(64 * GRP_WAVES), 0, s, p);
+    if (firstpos) hipLaunchKernelGGL((count_group_kernel<true, 0>), dim3(grid), dim3(64 * GRP_WAVES), 0, s, p);
+    else hipLaunchKernelGGL((count_group_kernel<false, 0>), dim3(grid), dim3(64 * GRP_WAVES), 0, s, p);
+}
+static void launch_group_positions(const CountParams &p, int grid, hipStream_t s)
+{
+    hipLaunchKernelGGL((count_group_kernel<false, 1>), dim3(grid), dim3(64 * GRP_WAVES), 0, s, p);
 }
 
 extern "C" {
@@ -975,7 +992,7 @@ void kaamer_workspace_free(kaamer_workspace *ws)
     void *bufs[] = { ws->d_q, ws->d_nq, ws->d_n_pos, ws->d_valid, ws->d_vals, ws->d_heads, ws->d_cnt3, ws->d_off3, ws->d_n6,
                      ws->d_tmp_meta, ws->d_orf_aa, ws->d_starts_alt, ws->d_q_start, ws->d_q_cnt, ws->d_pool_pid,
                      ws->d_pool_km, ws->d_pool_fp, ws->d_pool_cursor, ws->d_lists, ws->d_list_counts, ws->d_status_out, ws->d_stamps, ws->d_qinfo, ws->d_slots,
-                     ws->d_slot_off, ws->d_group_first, ws->d_n_groups, ws->d_g_keys,
+                     ws->d_slot_off, ws->d_group_first, ws->d_n_groups, ws->d_pos_words, ws->d_pos_base, ws->d_pos_off, ws->d_pos_bits, ws->d_g_keys,
                      ws->d_g_cnt, ws->d_g_min, ws->d_counter_replicas, ws->d_counters, ws->d_bsum, ws->d_bsum2, ws->d_hit_off,
                      ws->d_hit_pid, ws->d_hit_km, ws->d_hit_fp };
     for (void *b : bufs) if (b) (void)hipFree(b);
@@ -1020,8 +1037,8 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     ws->firstpos = opts->first_pos == 1 || (opts->first_pos == 0 && (opts->seq_type == KAAMER_NUCLEOTIDE || opts->seq_type == KAAMER_READS));
     int grp_per_cu = 0, p_per_cu = 0;
     hipError_t oe = ws->firstpos
-        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&grp_per_cu, count_group_kernel<true>, 64 * GRP_WAVES, 0)
-        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&grp_per_cu, count_group_kernel<false>, 64 * GRP_WAVES, 0);
+        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&grp_per_cu, count_group_kernel<true, 0>, 64 * GRP_WAVES, 0)
+        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&grp_per_cu, count_group_kernel<false, 0>, 64 * GRP_WAVES, 0);
     if (oe == hipSuccess) oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&p_per_cu, probe_kernel, 64 * P_WAVES, 0);
     if (oe != hipSuccess) { delete ws; return kaamer_fail(KAAMER_E_HIP, "occupancy query: %s", hipGetErrorString(oe)); }
     hipDeviceProp_t prop;
@@ -1076,6 +1093,14 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     if (!rc) rc = dev_alloc(&ws->d_slot_off, (size_t)ws->q_cap + 1);
     if (!rc) rc = dev_alloc(&ws->d_group_first, ws->groups_cap);
     if (!rc) rc = dev_alloc(&ws->d_n_groups, 1);
+    ws->want_positions = opts->want_positions != 0;
+    if (!rc && ws->want_positions) {
+        ws->bits_cap = opts->max_pos_words ? opts->max_pos_words : ws->hit_cap * 8;
+        rc = dev_alloc(&ws->d_pos_words, ws->q_cap);
+        if (!rc) rc = dev_alloc(&ws->d_pos_base, (size_t)ws->q_cap + 1);
+        if (!rc) rc = dev_alloc(&ws->d_pos_off, ws->hit_cap);
+        if (!rc) rc = dev_alloc(&ws->d_pos_bits, ws->bits_cap);
+    }
 #ifdef KAAMER_STAMPS
     if (!rc) rc = dev_alloc(&ws->d_stamps, 64);
     if (!rc) (void)hipMemset(ws->d_stamps, 0, 64 * sizeof(unsigned long long));
@@ -1261,10 +1286,13 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     HIPCHK(hipStreamWaitEvent(s, ws->ev_join, 0));
     CountParams pc = p;
     pc.ovf_list = list_ptr(LIST_G); pc.ovf_count = ws->d_list_counts + LIST_G;
+    pc.last_group_pass = ws->want_positions ? 0u : 1u;
+    uint64_t grp_blocks = 1;
     {
         // at most one workgroup per group; groups <= slots / GRP_BUDGET
         uint64_t gb = ((uint64_t)GRP_MIN_TABLE * nq_bound + 3 * pos_bound) / GRP_BUDGET + 1;
         if (gb > (uint64_t)ws->grp_grid) gb = ws->grp_grid;
+        grp_blocks = gb;
         launch_group(pc, (int)gb, ws->firstpos, s);
     }
     CountParams pg = p;
@@ -1290,6 +1318,32 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
                            ws->d_pool_pid, ws->d_pool_km, ws->d_pool_fp, ws->d_hit_pid, ws->d_hit_km, ws->d_hit_fp,
                            ws->hit_cap, status);
     }
+    if (ws->want_positions) {
+        // PositionHits bitmaps (search.go:442-452): layout from the final hit lists, then one more
+        // pass of the group kernel that sets one bit per (hit, position)
+        uint32_t gb = (nq_bound + 255) / 256;
+        if (gb < 1) gb = 1;
+        if (gb > (uint32_t)ws->n_cu * 8) gb = (uint32_t)ws->n_cu * 8;
+        hipLaunchKernelGGL(pos_words_kernel, dim3(gb), dim3(256), 0, s, ws->d_qinfo, ws->d_q_cnt, ws->d_nq, ws->d_pos_words);
+        if (nq_bound <= 8 * SCAN_TILE) {
+            hipLaunchKernelGGL(scan_single_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, ws->d_pos_words, ws->d_nq, ws->d_pos_base);
+        } else {
+            const uint32_t nsb = (uint32_t)(((uint64_t)nq_bound + 1 + SCAN_TILE - 1) / SCAN_TILE);
+            hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nsb), dim3(SCAN_BLOCK), 0, s, ws->d_pos_words, ws->d_nq, ws->d_bsum);
+            hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, ws->d_bsum, nsb);
+            hipLaunchKernelGGL(scan_apply_kernel, dim3(nsb), dim3(SCAN_BLOCK), 0, s, ws->d_pos_words, ws->d_nq, ws->d_bsum, ws->d_pos_base);
+        }
+        hipLaunchKernelGGL(pos_layout_kernel, dim3(ws->n_cu * 8), dim3(256), 0, s, ws->d_qinfo, ws->d_q_cnt, ws->d_hit_off,
+                           ws->d_pos_base, ws->d_nq, ws->d_pos_off, ws->d_pos_bits, ws->bits_cap, status);
+        CountParams pp2 = p;
+        pp2.last_group_pass = 1u;
+        pp2.hit_off = ws->d_hit_off;
+        pp2.hit_pid = ws->d_hit_pid;
+        pp2.pos_base = ws->d_pos_base;
+        pp2.pos_bits = ws->d_pos_bits;
+        pp2.ovf_list = list_ptr(LIST_SO); pp2.ovf_count = ws->d_list_counts + LIST_SO;
+        launch_group_positions(pp2, (int)grp_blocks, s);
+    }
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, s, ws->d_counter_replicas, ws->d_counters, ws->d_list_counts,
                        ws->d_status_out, ws->d_pool_cursor);
     HIPCHK(hipEventRecord(ev[4], s));
@@ -1308,6 +1362,9 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     out->d_orf_aa = nucl ? ws->d_orf_aa : nullptr;
     out->d_starts_alt = nucl ? ws->d_starts_alt : nullptr;
     out->d_counters = ws->d_counters;
+    out->d_pos_off = ws->want_positions ? ws->d_pos_off : nullptr;
+    out->d_pos_bits = ws->want_positions ? (const uint64_t *)ws->d_pos_bits : nullptr;
+    out->d_pos_base = ws->want_positions ? ws->d_pos_base : nullptr;
     return KAAMER_OK;
 }
 
@@ -1341,6 +1398,9 @@ int kaamer_workspace_finish(kaamer_workspace *ws, void *stream, kaamer_counters 
     if (status & ST_LIST_FULL) return kaamer_fail(KAAMER_E_CAPACITY, "tier work list exhausted");
     if (status & (ST_QUERY_CAP | ST_AA_CAP))
         return kaamer_fail(KAAMER_E_CAPACITY, "more ORFs than the workspace holds: raise workspace max_queries (now %u)", ws->q_cap);
+    if (status & ST_POS_CAP) return kaamer_fail(KAAMER_E_CAPACITY, "position bitmaps exceed the workspace: raise max_pos_words (now %llu)", (unsigned long long)ws->bits_cap);
+    if (status & ST_POS_UNSUPPORTED)
+        return kaamer_fail(KAAMER_E_CAPACITY, "position bitmaps are not available for queries with more distinct hits than an on-chip table holds (G tier)");
     if (status & ST_G_ARENA_FULL)
         return kaamer_fail(KAAMER_E_CAPACITY, "global counting arena exhausted: raise workspace g_tier_slots (now %llu)", (unsigned long long)ws->g_slots);
     if (status) return kaamer_fail(KAAMER_E_CAPACITY, "device status 0x%x", status);
@@ -1385,6 +1445,7 @@ struct batch_out_owner {
     std::vector<uint32_t> pid, km, fp;
     std::vector<uint8_t> orf_aa;
     std::vector<int32_t> starts_alt;
+    std::vector<uint64_t> pos_off, pos_bits;
 };
 
 static int search_batch_once(kaamer_index *ix, const kaamer_batch_in *in, uint64_t max_hits, uint64_t g_slots,
@@ -1399,6 +1460,8 @@ static int search_batch_once(kaamer_index *ix, const kaamer_batch_in *in, uint64
     o.g_tier_slots = g_slots;
     o.seq_type = in->seq_type;
     o.first_pos = 1;  // kaamer_batch_out always carries hit_first_pos
+    o.want_positions = in->want_positions ? 1u : 0u;
+    o.max_pos_words = max_hits * 8;
     o.max_queries = max_queries;
     kaamer_workspace *ws = nullptr;
     int rc = kaamer_workspace_create(ix, &o, &ws);
@@ -1437,6 +1500,13 @@ static int search_batch_once(kaamer_index *ix, const kaamer_batch_in *in, uint64
             if (e == hipSuccess) e = hipMemcpy(bo->fp.data(), dr.d_hit_first_pos, n_hits * 4, hipMemcpyDeviceToHost);
         }
     }
+    if (e == hipSuccess && ws->want_positions) {
+        uint64_t n_words = 0;
+        e = hipMemcpy(&n_words, ws->d_pos_base + nq, sizeof n_words, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) { bo->pos_off.resize(n_hits + 1); bo->pos_bits.resize(n_words + 1); }
+        if (e == hipSuccess && n_hits) e = hipMemcpy(bo->pos_off.data(), dr.d_pos_off, n_hits * 8, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && n_words) e = hipMemcpy(bo->pos_bits.data(), dr.d_pos_bits, n_words * 8, hipMemcpyDeviceToHost);
+    }
     if (e == hipSuccess && ws->nucleotide) {
         unsigned long long n_aa = 0;
         uint64_t n_sa = 0;
@@ -1456,6 +1526,7 @@ static int search_batch_once(kaamer_index *ix, const kaamer_batch_in *in, uint64
     bo->pub.hit_kmatch = bo->km.data();
     bo->pub.hit_first_pos = bo->fp.data();
     if (ws->nucleotide) { bo->pub.orf_aa = bo->orf_aa.data(); bo->pub.starts_alt = bo->starts_alt.data(); }
+    if (ws->want_positions) { bo->pub.pos_off = bo->pos_off.data(); bo->pub.pos_bits = bo->pos_bits.data(); }
     bo->pub.counters = c;
     *out = &bo->pub;
     bo = nullptr;
@@ -1471,7 +1542,6 @@ int kaamer_search_batch(kaamer_index *ix, const kaamer_batch_in *in, kaamer_batc
 {
     if (!ix || !in || !out || !in->offsets || (in->n_seqs && !in->seqs)) return kaamer_fail(KAAMER_E_ARG, "search_batch: bad argument");
     *out = nullptr;
-    if (in->want_positions) return kaamer_fail(KAAMER_E_ARG, "want_positions not supported yet");
     HIPCHK(hipSetDevice(ix->device));
     // The hit count of a batch is data dependent: start from a generous estimate and
     // enlarge on KAAMER_E_CAPACITY (the device reports it; results are never partial).

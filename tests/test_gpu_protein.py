@@ -239,3 +239,28 @@ def _from_ptr(ptr, n, dtype):
     rc = hip.hipMemcpy(out.ctypes.data, C.c_void_p(ptr), out.nbytes, 2)
     assert rc == 0
     return out
+
+
+def test_position_bitmaps(small, oracle):
+    """ExtractPositions: PositionHits[id][pos] (search.go:442-452) for every hit, bit-exact"""
+    from kaamer_amd import workload
+    db, img, ix, oix = small
+    q = workload.make_protein_queries(db, 60, seed=9)
+    seqs = workload.unpack(q) + [workload.unpack(db)[3], b"ACDEFGHIKLMNP", b"AAAA", max(workload.unpack(db), key=len)]
+    res = ix.search(seqs, want_positions=True)
+    exp = _oracle_hits(oix, oracle, seqs)
+    _check(res, exp)
+    n_bits = 0
+    for qi, s in enumerate(seqs):
+        size = oracle.size_in_kmer(s)
+        got = res.positions(qi)
+        if size < 7:
+            assert got == {}
+            continue
+        pid, km, pos = oix.search(s, want_positions=True)
+        assert sorted(got) == sorted(pid.tolist())
+        for i, p in enumerate(pid.tolist()):
+            assert got[p].tolist() == pos[i].tolist(), (qi, p)
+            assert int(got[p].sum()) == int(km[i])
+            n_bits += int(km[i])
+    assert n_bits == res.counters["n_post"]

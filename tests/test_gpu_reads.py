@@ -143,3 +143,22 @@ def test_reads_device_call_reuse(small, oracle):
                 a, b = int(hit_off[q]), int(hit_off[q + 1])
                 assert dict(zip(pid[a:b].tolist(), km[a:b].tolist())) == dict(zip(p.tolist(), k.tolist()))
                 q += 1
+
+
+def test_reads_position_bitmaps(small, oracle):
+    """reads always carry PositionHits in the reference (search.go:416); optional here"""
+    from kaamer_amd import workload
+    db, ix, oix = small
+    reads = workload.unpack(workload.make_reads(db, 120, seed=4))
+    res = ix.search(reads, seq_type=abi.READS, want_positions=True)
+    got_orfs = _gpu_orfs(res)
+    n = 0
+    for r, read in enumerate(reads):
+        for o in got_orfs.get(r, []):
+            pid, km, pos = oix.search(o["seq"], want_positions=True)
+            got = res.positions(o["q"])
+            assert sorted(got) == sorted(pid.tolist())
+            for i, p in enumerate(pid.tolist()):
+                assert got[p].tolist() == pos[i].tolist()
+                n += 1
+    assert n > 100
