@@ -186,8 +186,20 @@ def main():
     probe_s = tm["probe_ms"] / n_calls / 1e3
     count_s = tm["count_ms"] / n_calls / 1e3
     achieved = probe_bytes / probe_s / 1e9 if probe_s > 0 else 0.0
+    # HBM traffic from the PMC counters is collected in separate rocprofv3 passes (profiles/); it is
+    # reported here only when this run is the workload those passes measured
+    traffic = None
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_probe_kernel.json")))
+        if (pm["config"]["db_proteins"], pm["config"]["queries"], pm["config"]["workload"]) == \
+                (args.db_proteins, args.queries, args.workload):
+            traffic = pm["probe_kernel"]["traffic_bytes_per_launch"]
+    except Exception:
+        pass
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                "random_request_ceiling": {"G_requests_per_s": 51.0, "achieved_G_probes_per_s": c["n_probe"] / probe_s / 1e9 if probe_s > 0 else 0.0,
+                                           "source": "tools/random_read_bench.hip (profiles/r01_pmc_traffic_probe_kernel.json)"},
                 "kernel": "probe_kernel", "kernel_ms": probe_s * 1e3,
                 "algorithmic_bytes_per_launch": probe_bytes,
                 "bytes_per_lookup": probe_bytes / max(c["n_lookup"], 1),
