@@ -811,7 +811,7 @@ __global__ __launch_bounds__(256) void gather_hits_kernel(const uint32_t *d_nq, 
                                                           const uint64_t *q_start, const uint32_t *q_cnt,
                                                           const uint32_t *pool_pid, const uint32_t *pool_km,
                                                           const uint32_t *pool_fp, uint32_t *out_pid, uint32_t *out_km,
-                                                          uint32_t *out_fp, uint64_t out_cap, uint32_t *status)
+                                                          uint32_t *out_fp, uint64_t out_cap, uint32_t *status, int firstpos)
 {
     const uint32_t nq = *d_nq;
     const uint64_t n_hits = hit_off[nq];
@@ -826,7 +826,7 @@ __global__ __launch_bounds__(256) void gather_hits_kernel(const uint32_t *d_nq, 
         for (uint32_t i = lane; i < n; i += 64) {
             out_pid[d + i] = pool_pid[s + i];
             out_km[d + i] = pool_km[s + i];
-            out_fp[d + i] = pool_fp[s + i];
+            if (firstpos) out_fp[d + i] = pool_fp[s + i];
         }
     }
 }
@@ -1116,6 +1116,7 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     if (!rc) rc = dev_alloc(&ws->d_hit_pid, ws->hit_cap);
     if (!rc) rc = dev_alloc(&ws->d_hit_km, ws->hit_cap);
     if (!rc) rc = dev_alloc(&ws->d_hit_fp, ws->hit_cap);
+    if (!rc && hipMemset(ws->d_hit_fp, 0, ws->hit_cap * sizeof(uint32_t)) != hipSuccess) rc = kaamer_fail(KAAMER_E_HIP, "memset");
     if (rc) { kaamer_workspace_free(ws); return rc; }
     ws->ev = new (std::nothrow) std::vector<hipEvent_t>();
     if (!ws->ev) { kaamer_workspace_free(ws); return kaamer_fail(KAAMER_E_NOMEM, "event ring"); }
@@ -1166,6 +1167,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     const uint8_t *residues = d_seqs;   // what kernel P reads: the protein records, or the ORF amino acids
     uint64_t pos_bound = seq_bytes;     // host-side bound of the residue positions (grid sizing only)
     uint32_t nq_bound = n_seqs;         // host-side bound of the number of queries
+    const bool small_prep = false;
     if (!nucl) {
         hipLaunchKernelGGL(prep_protein_kernel, dim3((n_seqs + pb - 1) / pb > 0 ? (n_seqs + pb - 1) / pb : 1), dim3(pb), 0, s,
                            d_seqs, d_offsets, n_seqs, ws->d_q, ws->d_nq, ws->d_n_pos, ws->d_valid, ws->d_qinfo, ws->d_slots,
@@ -1208,6 +1210,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
 
     // ---- query groups: scan of the table capacities + first query of each group, on the side
     // stream beside kernels P and H (they only share prep's outputs)
+    if (!small_prep) {
     HIPCHK(hipEventRecord(ws->ev_fork, s));
     HIPCHK(hipStreamWaitEvent(ws->side, ws->ev_fork, 0));
     if (nq_bound <= 8 * SCAN_TILE) {
@@ -1226,6 +1229,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
                            ws->d_group_first, ws->d_n_groups, ws->groups_cap, status);
     }
     HIPCHK(hipEventRecord(ws->ev_join, ws->side));
+    }
 
     // ---- kernel P: flat probe
     ProbeParams pp;
@@ -1283,7 +1287,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     if (const char *e = getenv("KAAMER_ABLATE")) p.ablate = (uint32_t)atoi(e);
     auto list_ptr = [&](int which) { return ws->d_lists + (size_t)which * ws->q_cap; };
 
-    HIPCHK(hipStreamWaitEvent(s, ws->ev_join, 0));
+    if (!small_prep) HIPCHK(hipStreamWaitEvent(s, ws->ev_join, 0));
     CountParams pc = p;
     pc.ovf_list = list_ptr(LIST_G); pc.ovf_count = ws->d_list_counts + LIST_G;
     pc.last_group_pass = ws->want_positions ? 0u : 1u;
@@ -1316,7 +1320,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         if (gb > (uint32_t)ws->n_cu * 64) gb = (uint32_t)ws->n_cu * 64;
         hipLaunchKernelGGL(gather_hits_kernel, dim3(gb), dim3(256), 0, s, ws->d_nq, ws->d_hit_off, ws->d_q_start, ws->d_q_cnt,
                            ws->d_pool_pid, ws->d_pool_km, ws->d_pool_fp, ws->d_hit_pid, ws->d_hit_km, ws->d_hit_fp,
-                           ws->hit_cap, status);
+                           ws->hit_cap, status, ws->firstpos ? 1 : 0);
     }
     if (ws->want_positions) {
         // PositionHits bitmaps (search.go:442-452): layout from the final hit lists, then one more

@@ -147,6 +147,7 @@ def _device_search(ix, seqs, **ws_opts):
     buf, offs = api.pack_sequences(seqs)
     d_buf = torch.from_numpy(buf).cuda()
     d_off = torch.from_numpy(offs.view(np.int64)).cuda()
+    ws_opts.setdefault("first_pos", 1)
     ws = api.Workspace(ix, len(buf), len(seqs), **ws_opts)
     st = torch.cuda.current_stream().cuda_stream
     r = ws.search_device(d_buf.data_ptr(), d_off.data_ptr(), len(seqs), len(buf), stream=st)
