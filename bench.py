@@ -95,6 +95,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--check", type=int, default=50, help="queries checked against the oracle after timing")
+    ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
+                    help="N>1: replicas = every rank holds the table and its own batch (default; the DB fits one GPU); "
+                         "sharded = the table is split by hash prefix, all ranks search one common batch, partial hit "
+                         "lists are exchanged with one RCCL all-to-all and merged by the query's owner")
     args = ap.parse_args()
 
     if args.queries <= 0:
@@ -107,9 +111,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    sharded_mode = args.mode == "sharded"
+    if world > 1 or sharded_mode:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
     torch.cuda.set_device(local_rank)
 
@@ -119,7 +126,8 @@ def main():
     db = workload.make_db(args.db_proteins)
     log("DB: %d proteins, %d residues (%.1fs)" % (args.db_proteins, int(db[1][-1]), time.time() - t0))
     t0 = time.time()
-    img = api.Image.from_proteins(packed=db, load_factor=args.load_factor)
+    img = api.Image.from_proteins(packed=db, load_factor=args.load_factor,
+                                  shard=rank if sharded_mode else 0, n_shards=world if sharded_mode else 1)
     st = img.stats()
     log("image built in %.1fs: %s" % (time.time() - t0, st))
     t0 = time.time()
@@ -133,21 +141,29 @@ def main():
     if reads:
         q = workload.make_reads(db, args.queries, seed=workload.SEED + 2 + 1000 * rank)
     else:
-        q = workload.make_protein_queries(db, args.queries, seed=workload.SEED + 1 + 1000 * rank)
+        q = workload.make_protein_queries(db, args.queries, seed=workload.SEED + 1 + (0 if sharded_mode else 1000 * rank))
     qbuf, qoff = q
     d_buf = torch.from_numpy(qbuf).cuda()
     d_off = torch.from_numpy(qoff.view(np.int64)).cuda()
     ws = api.Workspace(ix, len(qbuf), args.queries, lds_slots=args.lds_slots,
                        seq_type=abi.READS if reads else abi.PROTEIN,
-                       max_hits=(64 << 20) if reads else 0)
+                       max_hits=(64 << 20) if reads else 0, first_pos=1 if sharded_mode else 0)
     stream = torch.cuda.current_stream().cuda_stream
+    if sharded_mode:
+        assert not reads, "sharded mode: protein workload only in this round"
+        from kaamer_amd import sharded
+        mws = api.Workspace(ix, len(qbuf), args.queries, first_pos=1, max_hits=16 << 20)
+        searcher = sharded.ShardedSearcher(ix, ws, mws, rank, world)
 
-    def step():
-        return ws.search_device(d_buf.data_ptr(), d_off.data_ptr(), args.queries, len(qbuf), stream=stream)
+        def step():
+            return searcher.step(d_buf, d_off, args.queries, len(qbuf), stream)
+    else:
+        def step():
+            return ws.search_device(d_buf.data_ptr(), d_off.data_ptr(), args.queries, len(qbuf), stream=stream)
 
     for _ in range(args.warmup):
         step()
-    counters = ws.finish(stream)  # also validates the batch (capacity / overflow)
+    counters = (mws if sharded_mode else ws).finish(stream)  # also validates the batch (capacity / overflow)
     ws.reset_timers()
 
     if world > 1:
@@ -160,12 +176,18 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
-    counters = ws.finish(stream)
+    if sharded_mode:
+        mws.finish(stream)
+        counters = step()[2]  # the local search's counters (one extra, untimed step)
+        mws.finish(stream)
+    else:
+        counters = ws.finish(stream)
     tm = ws.kernel_ms_sum()
     n_calls = max(tm["calls"], 1)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    lk = torch.tensor([float(counters["n_lookup"]), float(args.queries)], dtype=torch.float64, device="cuda")
+    lk = torch.tensor([float(counters["n_lookup"]), float(args.queries) / (world if sharded_mode else 1)],
+                      dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(lk, op=dist.ReduceOp.SUM)
@@ -212,13 +234,14 @@ def main():
     out = {
         "metric": "k-mer lookups/sec", "value": lookups_per_step * args.steps / elapsed,
         "unit": "k-mer lookups/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if sharded_mode else "weak",
         "vs_baseline": None, "dtype": "u32", "data": "synthetic",
         "config": {"workload": ("configs[2]: 6-frame path, %d synthetic 150-nt reads per GPU per step vs " if reads else
                                 "configs[1]: %d protein queries per GPU per step vs ") % args.queries +
                                "Swiss-Prot-sized synthetic DB (%d proteins, %d residues, %d distinct 7-mers) resident in HBM"
                                % (args.db_proteins, int(db[1][-1]), st["n_keys"]),
-                   "parallelism": "replicas x%d (no collective)" % world if world > 1 else "single GPU",
+                   "parallelism": ("hash-prefix shards x%d, one all-to-all of partial hit lists per batch" % world) if sharded_mode
+                                  else ("replicas x%d (no collective)" % world if world > 1 else "single GPU"),
                    "seed": workload.SEED},
         "query_seqs_per_s": queries_per_step * args.steps / elapsed,
         "counters_per_step_rank0": c,
@@ -226,7 +249,9 @@ def main():
     }
 
     if rank == 0:
-        want_cpu = not args.no_cpu_baseline and world == 1
+        want_cpu = not args.no_cpu_baseline and world == 1 and not sharded_mode
+        if sharded_mode:
+            args.check = 0
         if args.check or want_cpu:
             from oracle import oracle as O  # the checker / the reported CPU baseline, never the product
             t0 = time.time()
@@ -255,7 +280,7 @@ def main():
             if want_cpu:
                 out["cpu_baseline"] = cpu_baseline(oix, q, seconds=args.cpu_seconds, kind="reads" if reads else "protein")
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or sharded_mode:
         dist.barrier()
         dist.destroy_process_group()
 

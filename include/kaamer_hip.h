@@ -227,6 +227,15 @@ void kaamer_workspace_free(kaamer_workspace *ws);
 int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *d_seqs,
                          const uint64_t *d_offsets, uint32_t n_seqs, uint64_t seq_bytes,
                          int32_t seq_type, void *stream, kaamer_device_result *out);
+/* Sharded index (the table split by hash prefix over several devices): every shard
+ * searches the whole batch for the keys it owns, the partial hit lists travel to the
+ * query's owner (all-to-all, done by the caller), and the owner merges them here:
+ * entries [ent_off[q], ent_off[q+1]) are the partial (protein id, Kmatch, first position)
+ * of query q from all shards; Kmatch adds up, first positions take the minimum.
+ * Results (CSR) replace the workspace's last result; finish as after a search. */
+int kaamer_merge_device(kaamer_workspace *ws, const uint64_t *d_ent_off, const uint32_t *d_pid,
+                        const uint32_t *d_kmatch, const uint32_t *d_first_pos, uint32_t n_queries,
+                        uint64_t n_entries, void *stream, kaamer_device_result *out);
 /* Waits for `stream`, copies the counters to the host and reports a deferred
  * KAAMER_E_CAPACITY if a device-side bound was exceeded during the batch. */
 int kaamer_workspace_finish(kaamer_workspace *ws, void *stream, kaamer_counters *out);

@@ -101,6 +101,8 @@ SYMBOLS = {
     "kaamer_workspace_free": (None, [C.c_void_p]),
     "kaamer_search_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                        C.c_uint64, C.c_int32, C.c_void_p, C.POINTER(DeviceResult)]),
+    "kaamer_merge_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64,
+                                      C.c_void_p, C.POINTER(DeviceResult)]),
     "kaamer_workspace_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Counters)]),
     "kaamer_workspace_kernel_ms_sum": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                                  C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),

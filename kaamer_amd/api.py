@@ -218,6 +218,13 @@ class Workspace:
                                                  seq_bytes, seq_type, C.c_void_p(stream), C.byref(r)))
         return r
 
+    def merge_device(self, d_ent_off_ptr, d_pid_ptr, d_km_ptr, d_fp_ptr, n_queries, n_entries, stream=0):
+        """Merge partial hit lists (sharded index); same result object as search_device."""
+        r = abi.DeviceResult()
+        abi.check(abi.lib().kaamer_merge_device(self._h, d_ent_off_ptr, d_pid_ptr, d_km_ptr, d_fp_ptr, n_queries,
+                                                n_entries, C.c_void_p(stream), C.byref(r)))
+        return r
+
     def finish(self, stream=0):
         c = abi.Counters()
         abi.check(abi.lib().kaamer_workspace_finish(self._h, C.c_void_p(stream), C.byref(c)))

@@ -273,6 +273,8 @@ struct CountParams {
     const uint32_t *hit_pid;
     const uint64_t *pos_base;
     unsigned long long *pos_bits;
+    // merge of partial hit lists (count_group_kernel MODE 2)
+    const uint32_t *m_pid, *m_km, *m_fp;
     // tier input / overflow output lists
     const WorkItem *list;
     const uint32_t *list_count;
@@ -932,6 +934,10 @@ static void launch_group_positions(const CountParams &p, int grid, hipStream_t s
 {
     hipLaunchKernelGGL((count_group_kernel<false, 1>), dim3(grid), dim3(64 * GRP_WAVES), 0, s, p);
 }
+static void launch_group_merge(const CountParams &p, int grid, hipStream_t s)
+{
+    hipLaunchKernelGGL((count_group_kernel<true, 2>), dim3(grid), dim3(64 * GRP_WAVES), 0, s, p);
+}
 
 extern "C" {
 
@@ -1369,6 +1375,106 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     out->d_pos_off = ws->want_positions ? ws->d_pos_off : nullptr;
     out->d_pos_bits = ws->want_positions ? (const uint64_t *)ws->d_pos_bits : nullptr;
     out->d_pos_base = ws->want_positions ? ws->d_pos_base : nullptr;
+    return KAAMER_OK;
+}
+
+int kaamer_merge_device(kaamer_workspace *ws, const uint64_t *d_ent_off, const uint32_t *d_pid, const uint32_t *d_km,
+                        const uint32_t *d_fp, uint32_t n_queries, uint64_t n_entries, void *stream, kaamer_device_result *out)
+{
+    if (!ws || !out || (n_queries && !d_ent_off) || (n_entries && (!d_pid || !d_km || !d_fp)))
+        return kaamer_fail(KAAMER_E_ARG, "merge_device: bad argument");
+    if (n_queries > ws->q_cap) return kaamer_fail(KAAMER_E_CAPACITY, "merge of %u queries exceeds the workspace (%u)", n_queries, ws->q_cap);
+    if (n_entries > ws->hit_cap) return kaamer_fail(KAAMER_E_CAPACITY, "merge of %llu entries exceeds workspace max_hits", (unsigned long long)n_entries);
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipSetDevice(ws->device));
+    if (!ws->clean) {
+        HIPCHK(hipMemsetAsync(ws->d_pool_cursor, 0, (size_t)(POOL_SHARDS + 1) * CURSOR_STRIDE * sizeof(unsigned long long), s));
+        HIPCHK(hipMemsetAsync(ws->d_list_counts, 0, N_SMALL_SLOTS * sizeof(uint32_t), s));
+        HIPCHK(hipMemsetAsync(ws->d_counter_replicas, 0, sizeof(unsigned long long) * CTR_REPLICAS * CTR_N, s));
+        HIPCHK(hipMemsetAsync(ws->d_valid, 0, (size_t)(ws->pos_cap / 64 + 2) * sizeof(unsigned long long), s));
+        HIPCHK(hipMemsetAsync(ws->d_group_first, 0xFF, (size_t)ws->groups_cap * sizeof(uint32_t), s));
+    }
+    ws->clean = false;
+    uint32_t *status = ws->d_list_counts + SLOT_STATUS;
+    const uint32_t nq_bound = n_queries;
+    const int pb = 256;
+    hipLaunchKernelGGL(prep_merge_kernel, dim3((n_queries + pb - 1) / pb > 0 ? (n_queries + pb - 1) / pb : 1), dim3(pb), 0, s, d_ent_off,
+                       n_queries, ws->d_qinfo, ws->d_slots, ws->d_nq, ws->d_q_start, ws->d_q_cnt);
+    if (nq_bound <= 8 * SCAN_TILE) {
+        hipLaunchKernelGGL(scan_single_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, ws->d_slots, ws->d_nq, ws->d_slot_off);
+    } else {
+        const uint32_t nsb = (uint32_t)(((uint64_t)nq_bound + 1 + SCAN_TILE - 1) / SCAN_TILE);
+        hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nsb), dim3(SCAN_BLOCK), 0, s, ws->d_slots, ws->d_nq, ws->d_bsum2);
+        hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, ws->d_bsum2, nsb);
+        hipLaunchKernelGGL(scan_apply_kernel, dim3(nsb), dim3(SCAN_BLOCK), 0, s, ws->d_slots, ws->d_nq, ws->d_bsum2, ws->d_slot_off);
+    }
+    {
+        uint32_t gb = (nq_bound + 255) / 256;
+        if (gb < 1) gb = 1;
+        if (gb > (uint32_t)ws->n_cu * 8) gb = (uint32_t)ws->n_cu * 8;
+        hipLaunchKernelGGL(group_build_kernel, dim3(gb), dim3(256), 0, s, ws->d_qinfo, ws->d_slot_off, ws->d_nq, ws->d_group_first,
+                           ws->d_n_groups, ws->groups_cap, status);
+    }
+    CountParams p;
+    memset(&p, 0, sizeof p);
+    p.qinfo = ws->d_qinfo;
+    p.slot_off = ws->d_slot_off;
+    p.group_first = ws->d_group_first;
+    p.d_n_groups = ws->d_n_groups;
+    p.d_nq = ws->d_nq;
+    p.last_group_pass = 1u;
+    p.m_pid = d_pid; p.m_km = d_km; p.m_fp = d_fp;
+    p.list_cap = ws->q_cap;
+    p.q_start = ws->d_q_start;
+    p.q_cnt = ws->d_q_cnt;
+    p.pool_pid = ws->d_pool_pid; p.pool_km = ws->d_pool_km; p.pool_fp = ws->d_pool_fp;
+    p.pool_shard_cap = ws->pool_cap / POOL_SHARDS;
+    p.pool_cursor = ws->d_pool_cursor;
+    p.g_keys = ws->d_g_keys; p.g_cnt = ws->d_g_cnt; p.g_min = ws->d_g_min;
+    p.g_slots = ws->g_slots;
+    p.g_cursor = ws->d_pool_cursor + (size_t)POOL_SHARDS * CURSOR_STRIDE;
+    p.counters = ws->d_counter_replicas;
+    p.status = status;
+    auto list_ptr = [&](int which) { return ws->d_lists + (size_t)which * ws->q_cap; };
+    p.ovf_list = list_ptr(LIST_G); p.ovf_count = ws->d_list_counts + LIST_G;
+    {
+        uint64_t gb = ((uint64_t)GRP_MIN_TABLE * nq_bound + 3 * n_entries) / GRP_BUDGET + 1;
+        if (gb > (uint64_t)ws->grp_grid) gb = ws->grp_grid;
+        launch_group_merge(p, (int)gb, s);
+    }
+    CountParams pg = p;
+    pg.list = list_ptr(LIST_G); pg.list_count = ws->d_list_counts + LIST_G;
+    int g_grid = ws->g_grid;
+    if ((uint32_t)g_grid > nq_bound) g_grid = nq_bound > 0 ? (int)nq_bound : 1;
+    hipLaunchKernelGGL(merge_global_kernel, dim3(g_grid), dim3(256), 0, s, pg);
+    if (nq_bound <= 8 * SCAN_TILE) {
+        hipLaunchKernelGGL(scan_single_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, ws->d_q_cnt, ws->d_nq, ws->d_hit_off);
+    } else {
+        const uint32_t nsb = (uint32_t)(((uint64_t)nq_bound + 1 + SCAN_TILE - 1) / SCAN_TILE);
+        hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nsb), dim3(SCAN_BLOCK), 0, s, ws->d_q_cnt, ws->d_nq, ws->d_bsum);
+        hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, ws->d_bsum, nsb);
+        hipLaunchKernelGGL(scan_apply_kernel, dim3(nsb), dim3(SCAN_BLOCK), 0, s, ws->d_q_cnt, ws->d_nq, ws->d_bsum, ws->d_hit_off);
+    }
+    {
+        uint32_t gb = (nq_bound + 3) / 4;
+        if (gb < 1) gb = 1;
+        if (gb > (uint32_t)ws->n_cu * 64) gb = (uint32_t)ws->n_cu * 64;
+        hipLaunchKernelGGL(gather_hits_kernel, dim3(gb), dim3(256), 0, s, ws->d_nq, ws->d_hit_off, ws->d_q_start, ws->d_q_cnt,
+                           ws->d_pool_pid, ws->d_pool_km, ws->d_pool_fp, ws->d_hit_pid, ws->d_hit_km, ws->d_hit_fp,
+                           ws->hit_cap, status, 1);
+    }
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, s, ws->d_counter_replicas, ws->d_counters, ws->d_list_counts,
+                       ws->d_status_out, ws->d_pool_cursor);
+    HIPCHK(hipGetLastError());
+    ws->clean = true;
+    memset(out, 0, sizeof *out);
+    out->n_queries_cap = ws->q_cap;
+    out->d_n_queries = ws->d_nq;
+    out->d_hit_off = ws->d_hit_off;
+    out->d_hit_pid = ws->d_hit_pid;
+    out->d_hit_kmatch = ws->d_hit_km;
+    out->d_hit_first_pos = ws->d_hit_fp;
+    out->d_counters = ws->d_counters;
     return KAAMER_OK;
 }
 
