@@ -263,6 +263,32 @@ int64_t kaamer_filter_results(const uint32_t *kmatch_sorted, int64_t n_hits, int
  * ties (nondeterministic in the reference) are broken by ascending protein id. */
 void kaamer_sort_hits(const uint32_t *pid, const uint32_t *kmatch, int64_t n_hits, uint32_t *order);
 
+/* SetBestStartCodon, dna.go:198-272: hits in sortMapByValue order with their first
+ * matching positions; trims the ORF to the start codon preceding the first best-hit
+ * position.  Returns the residues trimmed (0 = unchanged); start_position and
+ * size_in_kmer are updated like dna.go:252-267. */
+int32_t kaamer_set_best_start_codon(const uint32_t *kmatch_sorted, const uint32_t *first_pos_sorted,
+                                    int64_t n_hits, const int32_t *starts_alt, int32_t n_starts,
+                                    int32_t plus_strand, const uint8_t *orf_aa, uint32_t aa_len,
+                                    int32_t *start_position, int32_t *size_in_kmer);
+
+/* ------------------------------------------------------------------------- */
+/* Readers — GetQueriesFasta / GetQueriesFastq (search.go:222-412) on a text   */
+/* buffer (already decompressed): packed sequences + SizeInKmer + names, with  */
+/* the reference's quirks (every FASTA record but the last is upper-cased; '*' */
+/* rule; FASTQ sequence lines must match ^[ATGCNatgcn]+$).                     */
+/* ------------------------------------------------------------------------- */
+typedef struct kaamer_reads kaamer_reads;
+int kaamer_parse_fasta(const char *text, uint64_t len, kaamer_reads **out);
+int kaamer_parse_fastq(const char *text, uint64_t len, kaamer_reads **out);
+uint32_t kaamer_reads_count(const kaamer_reads *r);
+const uint8_t *kaamer_reads_seqs(const kaamer_reads *r);
+const uint64_t *kaamer_reads_offsets(const kaamer_reads *r);       /* count + 1 */
+const int32_t *kaamer_reads_size_in_kmer(const kaamer_reads *r);
+const char *kaamer_reads_names(const kaamer_reads *r);
+const uint64_t *kaamer_reads_name_offsets(const kaamer_reads *r);  /* count + 1 */
+void kaamer_reads_free(kaamer_reads *r);
+
 #ifdef __cplusplus
 }
 #endif

@@ -109,6 +109,17 @@ SYMBOLS = {
     "kaamer_workspace_reset_timers": (None, [C.c_void_p]),
     "kaamer_filter_results": (C.c_int64, [C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_int64, C.c_int64]),
     "kaamer_sort_hits": (None, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "kaamer_set_best_start_codon": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32,
+                                                C.c_char_p, C.c_uint32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "kaamer_parse_fasta": (C.c_int, [C.c_char_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "kaamer_parse_fastq": (C.c_int, [C.c_char_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "kaamer_reads_count": (C.c_uint32, [C.c_void_p]),
+    "kaamer_reads_seqs": (C.POINTER(C.c_uint8), [C.c_void_p]),
+    "kaamer_reads_offsets": (C.POINTER(C.c_uint64), [C.c_void_p]),
+    "kaamer_reads_size_in_kmer": (C.POINTER(C.c_int32), [C.c_void_p]),
+    "kaamer_reads_names": (C.POINTER(C.c_char), [C.c_void_p]),
+    "kaamer_reads_name_offsets": (C.POINTER(C.c_uint64), [C.c_void_p]),
+    "kaamer_reads_free": (None, [C.c_void_p]),
 }
 
 _lib = None

@@ -249,3 +249,23 @@ class Workspace:
             self.close()
         except Exception:
             pass
+
+
+def parse_reads(text, fmt="fasta"):
+    """GetQueriesFasta / GetQueriesFastq on a text buffer -> list of dict(seq, name, size)"""
+    data = text.encode("latin-1") if isinstance(text, str) else bytes(text)
+    h = C.c_void_p()
+    f = abi.lib().kaamer_parse_fasta if fmt == "fasta" else abi.lib().kaamer_parse_fastq
+    abi.check(f(data, len(data), C.byref(h)))
+    try:
+        L = abi.lib()
+        n = L.kaamer_reads_count(h)
+        offs = np.ctypeslib.as_array(L.kaamer_reads_offsets(h), shape=(n + 1,)).copy()
+        noff = np.ctypeslib.as_array(L.kaamer_reads_name_offsets(h), shape=(n + 1,)).copy()
+        seqs = bytes(np.ctypeslib.as_array(L.kaamer_reads_seqs(h), shape=(int(offs[n]),))) if offs[n] else b""
+        names = bytes(np.ctypeslib.as_array(C.cast(L.kaamer_reads_names(h), C.POINTER(C.c_uint8)), shape=(int(noff[n]),))) if noff[n] else b""
+        size = np.ctypeslib.as_array(L.kaamer_reads_size_in_kmer(h), shape=(n,)).copy() if n else np.zeros(0, np.int32)
+        return [dict(seq=seqs[int(offs[i]):int(offs[i + 1])].decode("latin-1"),
+                     name=names[int(noff[i]):int(noff[i + 1])].decode("latin-1"), size=int(size[i])) for i in range(n)]
+    finally:
+        abi.lib().kaamer_reads_free(h)

@@ -146,3 +146,61 @@ def test_no_gpu_fails_loudly(klib):
     with pytest.raises(abi.KaamerError) as e:
         api.Index.from_image(img, 0)
     assert e.value.code == abi.E_HIP
+
+
+def test_readers_match_reference_restatement(klib):
+    """GetQueriesFasta / GetQueriesFastq (search.go:222-412) incl. the quirks"""
+    import random
+    import pyref
+    from kaamer_amd import api
+    rng = random.Random(8)
+    fasta = (">q1 first protein\nMKVLaagT\nACDEFGHIKL\n\n>q2\n  MELPNIMHPVAKLSTALAAALMLSGC*  \n>empty\n>q3 lower last\nmkvlaagtacdefgh\r\nik*\n")
+    got = api.parse_reads(fasta, "fasta")
+    exp = pyref.get_queries_fasta(fasta)
+    assert [(g["seq"], g["name"], g["size"]) for g in got] == [(e["seq"], e["name"], e["size"]) for e in exp]
+    assert got[0]["seq"] == "MKVLAAGTACDEFGHIKL" and got[-1]["seq"] == "mkvlaagtacdefghik*"   # last record keeps its case
+    assert got[1]["size"] == len(got[1]["seq"]) - 7
+    for _ in range(50):
+        recs = []
+        for i in range(rng.randint(0, 6)):
+            body = "".join(rng.choice("ACDEFGHIKLMNPQRSTVWYacdx* ") for _ in range(rng.randint(0, 90)))
+            lines = [body[j:j + 30] for j in range(0, len(body), 30)] + ([""] if rng.random() < 0.3 else [])
+            recs.append(">r%d desc\n" % i + "\n".join(lines))
+        text = "\n".join(recs) + ("\n" if rng.random() < 0.5 else "")
+        got = api.parse_reads(text, "fasta")
+        exp = pyref.get_queries_fasta(text)
+        assert [(g["seq"], g["name"], g["size"]) for g in got] == [(e["seq"], e["name"], e["size"]) for e in exp], text
+    fastq = "@r1\nACGTNacgtn\n+\nIIIIIIIIII\n@r2 x\nACGTTTGA\n+r2\n@@@@IIII\n\n@r3\nACGU\n+\nIIII\n@r4\nGGGG\n+\nACGT\n"
+    got = api.parse_reads(fastq, "fastq")
+    exp = pyref.get_queries_fastq(fastq)
+    assert [(g["seq"], g["name"], g["size"]) for g in got] == [(e["seq"], e["name"], e["size"]) for e in exp]
+    assert api.parse_reads("", "fasta") == [] and api.parse_reads("", "fastq") == []
+
+
+def test_set_best_start_codon_matches_oracle(klib, oracle):
+    """dna.go:198-272 from hit_first_pos vs the oracle's literal PositionHits scan"""
+    import ctypes as C
+    import random
+    rng = random.Random(5)
+    for _ in range(400):
+        n = rng.randint(21, 60)
+        seq = ("".join(rng.choice("ACDEFGHIKLMNPQRSTVWY") for _ in range(n - 1)) + rng.choice(["*", "A"])).encode()
+        size = oracle.size_in_kmer(seq)
+        nh = rng.randint(1, 5)
+        km = sorted((rng.randint(1, size) for _ in range(nh)), reverse=True)
+        if rng.random() < 0.4 and nh > 1:
+            km[1] = km[0]                                   # ties at the best score
+        pos = np.zeros((nh, size), dtype=bool)
+        for h in range(nh):
+            pos[h, rng.sample(range(size), km[h])] = True
+        starts = sorted(rng.sample(range(n), rng.randint(0, 4)))
+        plus = rng.random() < 0.5
+        sp0 = rng.randint(1, 500)
+        t, sp, so = oracle.set_best_start_codon(km, pos, size, starts, plus, seq, sp0)
+        kma = np.array(km, dtype=np.uint32)
+        fpa = np.array([int(np.argmax(pos[h])) for h in range(nh)], dtype=np.uint32)
+        sa = np.array(starts, dtype=np.int32)
+        c_sp, c_so = C.c_int32(sp0), C.c_int32(size)
+        got = klib.kaamer_set_best_start_codon(kma.ctypes.data, fpa.ctypes.data, nh, sa.ctypes.data if len(sa) else None,
+                                               len(sa), int(plus), seq, len(seq), C.byref(c_sp), C.byref(c_so))
+        assert (got, c_sp.value, c_so.value) == (t, sp, so)
