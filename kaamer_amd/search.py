@@ -1,0 +1,107 @@
+"""Host-side mirror of the reference's search drivers (pkg/search/search_protein.go,
+search_fastq.go, search_nucleotide.go) over the C ABI: same option names and defaults
+(api/server.go:139-152), same per-query flow, results as plain dicts shaped like the
+reference's JSON (docs/client.md:131-180).  All compute is in libkaamer_hip.so:
+readers, k-mer search, sort, FilterResults and SetBestStartCodon are C-ABI calls.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import abi, api
+
+PROTEIN_QUERY, DNA_QUERY = "Protein Query", "DNA Query"  # search.go:46-47
+
+
+@dataclass
+class SearchOptions:  # search.go:56-71 (the fields the hot path reads); defaults api/server.go:139-152
+    SequenceType: int = abi.PROTEIN
+    MaxResults: int = 10
+    MinKMatch: int = 10
+    MinKRatio: float = 0.05
+    ExtractPositions: bool = False
+
+
+def _sorted_hits(res, q):
+    """sortMapByValue (search.go:132-152): Kmatch descending (ties by protein id)"""
+    a, b = int(res.hit_off[q]), int(res.hit_off[q + 1])
+    pid = np.ascontiguousarray(res.hit_pid[a:b])
+    km = np.ascontiguousarray(res.hit_kmatch[a:b])
+    order = np.zeros(b - a, dtype=np.uint32)
+    abi.lib().kaamer_sort_hits(pid.ctypes.data, km.ctypes.data, b - a, order.ctypes.data)
+    return pid[order], km[order], np.ascontiguousarray(res.hit_first_pos[a:b])[order], order + a
+
+
+def _filter(km_sorted, size, o):
+    """FilterResults (search.go:189-220) -> number of hits kept"""
+    km = np.ascontiguousarray(km_sorted, dtype=np.uint32)
+    return int(abi.lib().kaamer_filter_results(km.ctypes.data, len(km), size, o.MinKRatio, o.MinKMatch, o.MaxResults))
+
+
+def ProteinSearch(index, fasta_text, options=None):
+    """search_protein.go:27-134 for one FASTA upload -> list of QueryResult dicts"""
+    o = options or SearchOptions(SequenceType=abi.PROTEIN)
+    queries = api.parse_reads(fasta_text, "fasta")
+    res = index.search([q["seq"] for q in queries], seq_type=abi.PROTEIN, want_positions=o.ExtractPositions)
+    out = []
+    for i, q in enumerate(queries):
+        if q["size"] < 7:  # search_protein.go:74-76
+            continue
+        pid, km, _, idx = _sorted_hits(res, i)
+        keep = _filter(km, q["size"], o)
+        if keep == 0:  # search_protein.go:108
+            continue
+        qr = {"Query": {"Sequence": q["seq"], "Name": q["name"], "SizeInKmer": q["size"], "Type": PROTEIN_QUERY,
+                        "Location": {"StartPosition": 1, "EndPosition": len(q["seq"]), "PlusStrand": True,
+                                     "StartsAlternative": []}, "Contig": ""},
+              "SearchResults": {"Hits": [{"Key": int(p), "Kmatch": int(k)} for p, k in zip(pid[:keep], km[:keep])]}}
+        if o.ExtractPositions:
+            pos = res.positions(i)
+            qr["SearchResults"]["PositionHits"] = {int(p): pos[int(p)].tolist() for p in pid[:keep]}
+        out.append(qr)
+    return out
+
+
+def _orf_results(index, reads, names, o, seq_type):
+    res = index.search(reads, seq_type=seq_type, want_positions=o.ExtractPositions)
+    out = []
+    for i in range(res.n_queries):
+        m = res.meta[i]
+        pid, km, fp, idx = _sorted_hits(res, i)
+        if len(km) == 0 or int(km[0]) < o.MinKMatch:  # search_fastq.go:119
+            continue
+        aa = bytes(res.orf_aa[int(m["aa_off"]):int(m["aa_off"]) + int(m["aa_len"])])
+        sa = np.ascontiguousarray(res.starts_alt[int(m["sa_off"]):int(m["sa_off"]) + int(m["sa_len"])], dtype=np.int32)
+        start, size = C.c_int32(int(m["start_position"])), C.c_int32(int(m["size_in_kmer"]))
+        kmc, fpc = np.ascontiguousarray(km, dtype=np.uint32), np.ascontiguousarray(fp, dtype=np.uint32)
+        trimmed = abi.lib().kaamer_set_best_start_codon(kmc.ctypes.data, fpc.ctypes.data, len(kmc),
+                                                        sa.ctypes.data if len(sa) else None, len(sa),
+                                                        int(m["plus_strand"]), aa, len(aa), C.byref(start), C.byref(size))
+        keep = _filter(km, size.value, o)  # on the possibly shrunk SizeInKmer (dna.go:263-266)
+        if keep == 0:
+            continue
+        out.append({"Query": {"Sequence": aa[trimmed:].decode("latin-1"), "Name": names[int(m["src_seq"])],
+                              "SizeInKmer": size.value, "Type": DNA_QUERY,
+                              "Location": {"StartPosition": start.value, "EndPosition": int(m["end_position"]),
+                                           "PlusStrand": bool(m["plus_strand"]), "StartsAlternative": []},
+                              "Contig": ""},
+                    "SearchResults": {"Hits": [{"Key": int(p), "Kmatch": int(k)} for p, k in zip(pid[:keep], km[:keep])]}})
+    return out
+
+
+def FastqSearch(index, fastq_text, options=None):
+    """search_fastq.go:27-154 (READS) -> list of QueryResult dicts, one per reported ORF"""
+    o = options or SearchOptions(SequenceType=abi.READS)
+    recs = api.parse_reads(fastq_text, "fastq")
+    return _orf_results(index, [r["seq"] for r in recs], [r["name"] for r in recs], o, abi.READS)
+
+
+def NucleotideSearch(index, fasta_text, options=None):
+    """search_nucleotide.go:27-160 (contigs in FASTA) -> list of QueryResult dicts"""
+    o = options or SearchOptions(SequenceType=abi.NUCLEOTIDE)
+    recs = api.parse_reads(fasta_text, "fasta")
+    out = _orf_results(index, [r["seq"] for r in recs], [r["name"] for r in recs], o, abi.NUCLEOTIDE)
+    for qr in out:
+        qr["Query"]["Contig"] = qr["Query"]["Name"]  # search.go:305-306
+    return out
