@@ -2,24 +2,28 @@
 //
 // What runs on the device, per batch (all on the caller's stream, no host sync):
 //
-//   prep_protein_kernel   Query.SizeInKmer etc. for protein records
-//                         (search.go:290-293; search_protein.go:70-76) and the
-//                         tier work lists
-//   lds_tier_kernel       THE hot loop: sliding 7-mer encode (k_store.go:91-117,
-//                         search_protein.go:94-98), bucket probe (replaces the
-//                         two Badger point reads of search.go:421-429), postings
-//                         expansion and per-protein counting (search.go:431-436,
-//                         442-452) in an LDS hash table, ballot/prefix-sum
-//                         compaction of the hit list.  Two instantiations:
-//                           S tier: one wave per query (short queries)
-//                           L tier: one 16-wave workgroup per query (long
-//                                   queries and S-tier overflows), 4096 slots
-//   global_tier_kernel    G tier: queries whose distinct hits exceed the L table
-//                         count into an exactly sized table in HBM
-//   scan / gather kernels hit lists -> CSR in query order
+//   translate_kernel x2 + orf_order_kernel   nucleotide input only (translate.hip.inc):
+//                         GetORFs (dna.go:65-181) -> ORF batch
+//   prep_protein_kernel / prep_orf_kernel    Query.SizeInKmer etc. (search.go:290-293;
+//                         search_protein.go:70-76), the bitmap of positions that start no
+//                         k-mer, an LDS table capacity per query
+//   scan + group_build_kernel                packs consecutive queries into groups (side
+//                         stream, beside the probe kernel)
+//   probe_kernel          the dominant kernel: flat over residue positions; sliding 7-mer
+//                         encode (k_store.go:91-117, search_protein.go:94-98) and bucket
+//                         probe (replaces KmerStore.Get, search.go:421) -> vals[pos]
+//   count_group_kernel    (count_group.hip.inc) postings expansion + Counter increments
+//                         (search.go:427-436, 442-452) in LDS hash tables, one 8-wave
+//                         workgroup per query group; ballot/popcount compaction
+//   count_global_kernel   G tier: queries whose distinct hits exceed their LDS table count
+//                         into an exactly sized table in HBM
+//   scan + gather_hits_kernel                hit lists -> CSR in query order
+//   [positions pass]      PositionHits bitmaps when asked for
+//   finalize_kernel       counters, status, and all per-batch state left zeroed
 //
-// This is integer hashing/indexing: no MFMA; the bound is HBM (random 64-byte
-// bucket reads + postings).
+// This is integer hashing/indexing: no MFMA.  The probe is bound by the memory system's
+// random-request rate (~51e9 requests/s on MI355X whatever the size up to 128 B,
+// tools/random_read_bench.hip), i.e. ~3.3 TB/s for 64-byte buckets.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -233,34 +237,12 @@ __global__ __launch_bounds__(64 * P_WAVES) void probe_kernel(ProbeParams p)
 }
 
 // ====================================================================================
-// Kernel H — flat fetch of the postings heads
-// ====================================================================================
-// Position-parallel again: heads[i] = {count, id0, id1, id2} of the k-mer at position i
-// (count 0: absent; inline single: {1, id}); lists longer than three ids keep their
-// remaining ids in the arena at vals[i]*16 + 16.  Moves the random 16-byte head reads out
-// of the per-query chain into a balanced, fully occupied kernel.
-__global__ __launch_bounds__(256) void heads_kernel(const uint32_t *vals, const uint32_t *arena,
-                                                    const unsigned long long *d_n_pos, uint4 *heads)
-{
-    const unsigned long long n_pos = *d_n_pos;
-    for (unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_pos;
-         i += (unsigned long long)gridDim.x * blockDim.x) {
-        const uint32_t v = vals[i];
-        uint4 h = make_uint4(0, 0, 0, 0);
-        if (v & KH_INLINE_BIT) h = make_uint4(1u, v & ~KH_INLINE_BIT, 0, 0);
-        else if (v != 0u) h = reinterpret_cast<const uint4 *>(arena)[v];
-        heads[i] = h;
-    }
-}
-
-// ====================================================================================
 // Kernel C — per-query counting (postings expansion + Counter increments)
 // ====================================================================================
 struct QInfo;
 struct CountParams {
     const uint32_t *arena;
     const uint32_t *vals;  // from kernel P, indexed like the residue buffer
-    const uint4 *heads;    // from kernel H: {count, id0, id1, id2} per position
     // query groups (count_group.hip.inc)
     const struct QInfo *qinfo;
     const uint64_t *slot_off;   // exclusive scan of the table capacities
@@ -412,7 +394,7 @@ __device__ __forceinline__ bool add_runs(const Table &tab, uint32_t x, uint32_t 
 // c0 + k*stride.  `s_pref` is 64 words of LDS private to the wave.  No workgroup
 // barriers inside.  COUNT_ONLY: only sum the postings (G tier sizing pass).
 template <class Table, int NWIN, bool COUNT_ONLY>
-__device__ __forceinline__ bool count_windows(const CountParams &p, const uint32_t *vals, const uint4 *heads,
+__device__ __forceinline__ bool count_windows(const CountParams &p, const uint32_t *vals,
                                               int32_t size, int32_t c0, int32_t stride, const Table &tab, PostCtr &c,
                                               volatile uint32_t *s_pref KSTAMP_ARG)
 {
@@ -424,7 +406,11 @@ __device__ __forceinline__ bool count_windows(const CountParams &p, const uint32
         const int32_t pos = c0 + k * stride + (int32_t)lane;
         v[k] = 0u;
         h[k] = make_uint4(0, 0, 0, 0);
-        if (pos < size) { v[k] = vals[pos]; h[k] = heads[pos]; }
+        if (pos < size) {
+            v[k] = vals[pos];
+            if (v[k] & KH_INLINE_BIT) h[k] = make_uint4(1u, v[k] & ~KH_INLINE_BIT, 0, 0);
+            else if (v[k] != 0u) h[k] = reinterpret_cast<const uint4 *>(p.arena)[v[k]];  // {count, id0, id1, id2}
+        }
     }
     KSTAMP(2);
     bool ok = true;
@@ -549,13 +535,12 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
         const uint32_t q = wi.q;
         const int32_t size = wi.size;
         const uint32_t *vals = p.vals + wi.aa_off;
-        const uint4 *heads = p.heads + wi.aa_off;
         if (tid == 0) { s_nd = 0; s_fail = 0; s_post = 0; s_cursor = 0; }
         __syncthreads();
         // pass 1: exact number of postings (an upper bound of the distinct proteins)
         pc.clear();
         for (int32_t r0 = 0; r0 < size; r0 += 64 * WAVES * NWIN)
-            count_windows<NullTable, NWIN, true>(p, vals, heads, size, r0 + 64 * (int32_t)wv, 64 * WAVES, nt, pc, s_pref[wv] KSTAMP_PASS);
+            count_windows<NullTable, NWIN, true>(p, vals, size, r0 + 64 * (int32_t)wv, 64 * WAVES, nt, pc, s_pref[wv] KSTAMP_PASS);
         {
             const unsigned long long wp = wave_total(pc.post);
             if (lane == 0 && wp) atomicAdd(&s_post, wp);
@@ -586,7 +571,7 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
         // pass 2: count
         pc.clear();
         for (int32_t r0 = 0; r0 < size; r0 += 64 * WAVES * NWIN) {
-            const bool ok = count_windows<GlobalTable, NWIN, false>(p, vals, heads, size, r0 + 64 * (int32_t)wv, 64 * WAVES, gt,
+            const bool ok = count_windows<GlobalTable, NWIN, false>(p, vals, size, r0 + 64 * (int32_t)wv, 64 * WAVES, gt,
                                                                    pc, s_pref[wv] KSTAMP_PASS);
             if (!ok) s_fail = 1;
         }
@@ -879,7 +864,6 @@ struct kaamer_workspace {
     uint32_t *d_n_groups;
     uint32_t groups_cap;
     int grp_grid;
-    uint4 *d_heads;                     // postings heads per residue position
     // nucleotide / reads input: 6-frame translation products
     bool nucleotide;
     uint64_t aa_cap, sa_cap;
@@ -995,7 +979,7 @@ void kaamer_workspace_free(kaamer_workspace *ws)
 {
     if (!ws) return;
     (void)hipSetDevice(ws->device);
-    void *bufs[] = { ws->d_q, ws->d_nq, ws->d_n_pos, ws->d_valid, ws->d_vals, ws->d_heads, ws->d_cnt3, ws->d_off3, ws->d_n6,
+    void *bufs[] = { ws->d_q, ws->d_nq, ws->d_n_pos, ws->d_valid, ws->d_vals, ws->d_cnt3, ws->d_off3, ws->d_n6,
                      ws->d_tmp_meta, ws->d_orf_aa, ws->d_starts_alt, ws->d_q_start, ws->d_q_cnt, ws->d_pool_pid,
                      ws->d_pool_km, ws->d_pool_fp, ws->d_pool_cursor, ws->d_lists, ws->d_list_counts, ws->d_status_out, ws->d_stamps, ws->d_qinfo, ws->d_slots,
                      ws->d_slot_off, ws->d_group_first, ws->d_n_groups, ws->d_pos_words, ws->d_pos_base, ws->d_pos_off, ws->d_pos_bits, ws->d_g_keys,
@@ -1075,7 +1059,6 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     if (!rc) rc = dev_alloc(&ws->d_n_pos, 1);
     if (!rc) rc = dev_alloc(&ws->d_valid, (size_t)(ws->pos_cap / 64 + 2));
     if (!rc) rc = dev_alloc(&ws->d_vals, (size_t)ws->pos_cap);
-    if (!rc) rc = dev_alloc(&ws->d_heads, (size_t)ws->pos_cap);
     if (!rc && ws->nucleotide) {
         const size_t n6 = (size_t)ws->max_seqs * 6;
         rc = dev_alloc(&ws->d_cnt3, 3 * n6);
@@ -1254,19 +1237,11 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     HIPCHK(hipEventRecord(ev[1], s));
     hipLaunchKernelGGL(probe_kernel, dim3((unsigned)p_blocks), dim3(64 * P_WAVES), 0, s, pp);
     HIPCHK(hipEventRecord(ev[2], s));
-    {
-        uint64_t hb = (pos_bound + 255) / 256;
-        if (hb > (uint64_t)ws->n_cu * 8) hb = (uint64_t)ws->n_cu * 8;
-        if (hb < 1) hb = 1;
-        hipLaunchKernelGGL(heads_kernel, dim3((unsigned)hb), dim3(256), 0, s, ws->d_vals, ix->d_arena, ws->d_n_pos, ws->d_heads);
-    }
-
     // ---- kernel C: counting
     CountParams p;
     memset(&p, 0, sizeof p);
     p.arena = ix->d_arena;
     p.vals = ws->d_vals;
-    p.heads = ws->d_heads;
     p.qinfo = ws->d_qinfo;
     p.slot_off = ws->d_slot_off;
     p.group_first = ws->d_group_first;
