@@ -155,43 +155,61 @@ __global__ __launch_bounds__(64 * P_WAVES) void probe_kernel(ProbeParams p)
     const unsigned long long n_pos = *p.d_n_pos;
     const unsigned long long n_win = (n_pos + 63) >> 6;
     for (uint32_t i = tid; i < 256; i += 64 * P_WAVES) s_lut[i] = (uint8_t)kh_residue_code((uint8_t)i);
+    __syncthreads();  // the only workgroup barrier: the waves run independently from here on
     uint32_t c_lookup = 0, c_probe = 0, c_found = 0;
+    uint8_t *stage = s_stage[wv];
 
-    for (unsigned long long w0 = (unsigned long long)blockIdx.x * P_WAVES; w0 < n_win; w0 += (unsigned long long)gridDim.x * P_WAVES) {
-        const unsigned long long w = w0 + wv;
-        const bool live = w < n_win;
+    const unsigned long long stride = (unsigned long long)gridDim.x * P_WAVES;
+    unsigned long long w = (unsigned long long)blockIdx.x * P_WAVES + wv;
+    // software pipeline: the bitmap word and the residues of the NEXT window are in flight
+    // while the buckets of the current one are fetched
+    unsigned long long mask = 0;
+    uint32_t ra = 0, rb = 0;
+    auto fetch = [&](unsigned long long win, unsigned long long &m, uint32_t &a, uint32_t &b) {
+        m = 0; a = 0; b = 0;
+        if (win < n_win) {
+            m = ~p.invalid[win];
+            const unsigned long long i0 = (win << 6) + lane;
+            if (i0 < n_pos) a = p.residues[i0];
+            if (lane < 6 && i0 + 64 < n_pos) b = p.residues[i0 + 64];
+        }
+    };
+    fetch(w, mask, ra, rb);
+
+    for (; w < n_win; w += stride) {
         const unsigned long long base = w << 6;
-        unsigned long long mask = 0ull;
-        if (live) {
-            mask = ~p.invalid[w];
-            if (lane == 0 && mask != ~0ull) p.invalid[w] = 0ull;  // leave the bitmap clean for the next batch
-        }
-        __syncthreads();  // stage reuse + LUT ready
-        if (mask) {
-            const unsigned long long i0 = base + lane;
-            s_stage[wv][lane] = (i0 < n_pos) ? s_lut[p.residues[i0]] : (uint8_t)KH_CODE_UNKNOWN;
-            if (lane < 6) s_stage[wv][64 + lane] = (i0 + 64 < n_pos) ? s_lut[p.residues[i0 + 64]] : (uint8_t)KH_CODE_UNKNOWN;
-        }
-        __syncthreads();
+        unsigned long long nmask;
+        uint32_t na, nb;
+        fetch(w + stride, nmask, na, nb);
+        if (lane == 0 && mask != ~0ull) p.invalid[w] = 0ull;  // leave the bitmap clean for the next batch
+
         uint32_t key = KH_EMPTY_KEY;
-        if ((mask >> lane) & 1ull) {
-            const uint8_t *st = s_stage[wv] + lane;
-            key = kh_key_from_codes(st[0], st[1], st[2], st[3], st[4], st[5], st[6]);
-            // sharded index: this device probes only the keys it owns
-            if (p.n_shards > 1 && kh_shard_of(key, p.n_shards) != p.shard) key = KH_EMPTY_KEY;
+        if (mask) {
+            stage[lane] = (base + lane < n_pos) ? s_lut[ra] : (uint8_t)KH_CODE_UNKNOWN;
+            if (lane < 6) stage[64 + lane] = (base + 64 + lane < n_pos) ? s_lut[rb] : (uint8_t)KH_CODE_UNKNOWN;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if ((mask >> lane) & 1ull) {
+                const uint8_t *st = stage + lane;
+                key = kh_key_from_codes(st[0], st[1], st[2], st[3], st[4], st[5], st[6]);
+                // sharded index: this device probes only the keys it owns
+                if (p.n_shards > 1 && kh_shard_of(key, p.n_shards) != p.shard) key = KH_EMPTY_KEY;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
         const uint32_t bucket = (key != KH_EMPTY_KEY) ? (uint32_t)kh_home_bucket(key, p.n_shards, p.n_buckets) : 0u;
 
         // round j serves the k-mers of lanes 16j..16j+15; lane 4g+j ends up owning k-mer 16j+g
         uint4 ld[4];
-        uint32_t rkey[4], rb[4];
+        uint32_t rkey[4], rbk[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int src = 16 * j + (int)(lane >> 2);
-            rb[j] = __shfl(bucket, src, 64);
+            rbk[j] = __shfl(bucket, src, 64);
             rkey[j] = __shfl(key, src, 64);
             ld[j] = make_uint4(KH_EMPTY_KEY, 0, KH_EMPTY_KEY, 0);
-            if (rkey[j] != KH_EMPTY_KEY) ld[j] = p.table[(uint64_t)rb[j] * 4 + (lane & 3u)];
+            if (rkey[j] != KH_EMPTY_KEY) ld[j] = p.table[(uint64_t)rbk[j] * 4 + (lane & 3u)];
         }
         uint32_t okey = KH_EMPTY_KEY, oval = 0, obucket = 0;
         bool oempty = true;
@@ -202,7 +220,7 @@ __global__ __launch_bounds__(64 * P_WAVES) void probe_kernel(ProbeParams p)
             uint32_t e = (ld[j].x == KH_EMPTY_KEY || ld[j].z == KH_EMPTY_KEY) ? 1u : 0u;
             r |= __shfl_xor(r, 1, 64); e |= __shfl_xor(e, 1, 64);
             r |= __shfl_xor(r, 2, 64); e |= __shfl_xor(e, 2, 64);
-            if ((lane & 3u) == (uint32_t)j) { okey = kk; oval = r; oempty = (e != 0u); obucket = rb[j]; }
+            if ((lane & 3u) == (uint32_t)j) { okey = kk; oval = r; oempty = (e != 0u); obucket = rbk[j]; }
         }
         const bool valid = okey != KH_EMPTY_KEY;
         if (valid) { c_lookup++; c_probe++; }
@@ -225,7 +243,9 @@ __global__ __launch_bounds__(64 * P_WAVES) void probe_kernel(ProbeParams p)
         if (valid && oval != 0u) c_found++;
         // the owner lane writes the position it owns: 16*(lane&3) + (lane>>2)
         const unsigned long long opos = base + 16u * (lane & 3u) + (lane >> 2);
-        if (live && opos < n_pos) p.vals[opos] = valid ? oval : 0u;
+        if (opos < n_pos) p.vals[opos] = valid ? oval : 0u;
+
+        mask = nmask; ra = na; rb = nb;
     }
     const uint32_t t_lookup = wave_total(c_lookup), t_probe = wave_total(c_probe), t_found = wave_total(c_found);
     if (lane == 0) {
