@@ -157,7 +157,9 @@ typedef struct {
 typedef struct {
     uint32_t n_queries;
     const kaamer_query_meta *q;
-    const uint64_t *hit_off;     /* CSR over queries, n_queries + 1            */
+    const uint64_t *hit_off;     /* CSR: hits of query i are [hit_off[i],      */
+                                 /* hit_off[i+1]); n_queries + 1 entries       */
+    const uint32_t *hit_cnt;     /* hits of each query                         */
     const uint32_t *hit_pid;     /* Hit.Key      (search.go:111-115)           */
     const uint32_t *hit_kmatch;  /* Hit.Kmatch; unsorted within a query        */
     const uint32_t *hit_first_pos; /* lowest query position that matched the   */
@@ -188,11 +190,6 @@ typedef struct {
     uint32_t max_seqs;       /* most input sequences per batch                 */
     uint32_t max_queries;    /* most queries (ORFs) per batch; 0 = derive      */
     uint64_t max_hits;       /* most (query,protein) pairs per batch; 0=derive */
-    uint32_t lds_slots;      /* S-tier on-chip counting table slots per query  */
-                             /* (power of two, 64..2048); 0 = default 512      */
-    uint32_t s_tier_max_kmers; /* queries up to this SizeInKmer run one wave   */
-                             /* per query, longer ones a 16-wave workgroup;    */
-                             /* 0 = default                                    */
     uint64_t g_tier_slots;   /* HBM counting-table slots for queries whose     */
                              /* distinct hits exceed the on-chip tiers; 0 = def*/
     int32_t seq_type;        /* KAAMER_PROTEIN, or KAAMER_NUCLEOTIDE / READS   */
@@ -201,7 +198,11 @@ typedef struct {
                              /* PositionHits (nucleotide/reads only,           */
                              /* search.go:416), 1 = always, 2 = never (zeros)  */
     uint32_t want_positions; /* full PositionHits bitmaps (ExtractPositions)   */
-    uint32_t reserved;
+    uint32_t compact;        /* 1: finish with the hit lists packed in query   */
+                             /* order (hit_off is a CSR offset array, one more */
+                             /* scan + copy pass); 0: leave every list where   */
+                             /* the counting kernel wrote it (hit_off[q],      */
+                             /* hit_cnt[q] address a sparse array)             */
     uint64_t max_pos_words;  /* u64 words of bitmap storage; 0 = 8 x max_hits  */
 } kaamer_workspace_opts;
 
@@ -209,7 +210,10 @@ typedef struct {
     uint32_t n_queries_cap;
     const uint32_t *d_n_queries;        /* device scalar                       */
     const kaamer_query_meta *d_q;
-    const uint64_t *d_hit_off;          /* n_queries + 1                       */
+    const uint64_t *d_hit_off;          /* first hit of each query; with       */
+                                        /* opts.compact also [n] = total (CSR) */
+    const uint32_t *d_hit_cnt;          /* n_queries: hits of each query       */
+    uint64_t hit_capacity;              /* entries of the three hit arrays     */
     const uint32_t *d_hit_pid;
     const uint32_t *d_hit_kmatch;
     const uint32_t *d_hit_first_pos;

@@ -54,7 +54,7 @@ class BatchIn(C.Structure):
 
 class BatchOut(C.Structure):
     _fields_ = [("n_queries", C.c_uint32), ("q", C.POINTER(QueryMeta)),
-                ("hit_off", C.POINTER(C.c_uint64)), ("hit_pid", C.POINTER(C.c_uint32)),
+                ("hit_off", C.POINTER(C.c_uint64)), ("hit_cnt", C.POINTER(C.c_uint32)), ("hit_pid", C.POINTER(C.c_uint32)),
                 ("hit_kmatch", C.POINTER(C.c_uint32)), ("hit_first_pos", C.POINTER(C.c_uint32)),
                 ("pos_off", C.POINTER(C.c_uint64)), ("pos_bits", C.POINTER(C.c_uint64)),
                 ("orf_aa", C.POINTER(C.c_uint8)), ("starts_alt", C.POINTER(C.c_int32)),
@@ -63,14 +63,15 @@ class BatchOut(C.Structure):
 
 class WorkspaceOpts(C.Structure):
     _fields_ = [("max_seq_bytes", C.c_uint64), ("max_seqs", C.c_uint32), ("max_queries", C.c_uint32),
-                ("max_hits", C.c_uint64), ("lds_slots", C.c_uint32), ("s_tier_max_kmers", C.c_uint32),
+                ("max_hits", C.c_uint64),
                 ("g_tier_slots", C.c_uint64), ("seq_type", C.c_int32), ("first_pos", C.c_uint32), ("want_positions", C.c_uint32),
-                ("reserved", C.c_uint32), ("max_pos_words", C.c_uint64)]
+                ("compact", C.c_uint32), ("max_pos_words", C.c_uint64)]
 
 
 class DeviceResult(C.Structure):
     _fields_ = [("n_queries_cap", C.c_uint32), ("d_n_queries", C.c_void_p), ("d_q", C.c_void_p),
-                ("d_hit_off", C.c_void_p), ("d_hit_pid", C.c_void_p), ("d_hit_kmatch", C.c_void_p),
+                ("d_hit_off", C.c_void_p), ("d_hit_cnt", C.c_void_p), ("hit_capacity", C.c_uint64), ("d_hit_pid", C.c_void_p),
+                ("d_hit_kmatch", C.c_void_p),
                 ("d_hit_first_pos", C.c_void_p), ("d_orf_aa", C.c_void_p), ("d_starts_alt", C.c_void_p),
                 ("d_counters", C.c_void_p), ("d_pos_off", C.c_void_p), ("d_pos_bits", C.c_void_p),
                 ("d_pos_base", C.c_void_p)]

@@ -103,6 +103,7 @@ class BatchResult:
                                         ("end_position", "<i4"), ("plus_strand", "<i4"), ("aa_len", "<u4"),
                                         ("aa_off", "<u8"), ("sa_off", "<u4"), ("sa_len", "<u4")]))
         self.hit_off = np.ctypeslib.as_array(o.hit_off, shape=(n + 1,)).copy()
+        self.hit_cnt = np.ctypeslib.as_array(o.hit_cnt, shape=(n,)).copy() if n else np.zeros(0, np.uint32)
         nh = int(self.hit_off[n])
         z = np.zeros(0, np.uint32)
         self.hit_pid = np.ctypeslib.as_array(o.hit_pid, shape=(nh,)).copy() if nh else z
@@ -113,18 +114,24 @@ class BatchResult:
         if bool(o.pos_off) and bool(o.pos_bits):
             self.pos_off = np.ctypeslib.as_array(o.pos_off, shape=(nh,)).copy() if nh else np.zeros(0, np.uint64)
             nw = 0
-            if nh:
-                last_q = int(np.searchsorted(self.hit_off, nh - 1, side="right")) - 1
-                nw = int(self.pos_off[nh - 1]) + (int(self.meta["size_in_kmer"][last_q]) + 63) // 64
+            for q in range(n):  # words in use = end of the last bitmap
+                if self.hit_cnt[q]:
+                    last = int(self.hit_off[q]) + int(self.hit_cnt[q]) - 1
+                    nw = max(nw, int(self.pos_off[last]) + (int(self.meta["size_in_kmer"][q]) + 63) // 64)
             self.pos_bits = np.ctypeslib.as_array(o.pos_bits, shape=(nw,)).copy() if nw else np.zeros(0, np.uint64)
         aa_len = int((self.meta["aa_off"] + self.meta["aa_len"]).max()) if n and bool(o.orf_aa) else 0
         self.orf_aa = np.ctypeslib.as_array(o.orf_aa, shape=(aa_len,)).copy() if aa_len else np.zeros(0, np.uint8)
         sa_len = int((self.meta["sa_off"] + self.meta["sa_len"]).max()) if n and bool(o.starts_alt) else 0
         self.starts_alt = np.ctypeslib.as_array(o.starts_alt, shape=(sa_len,)).copy() if sa_len else np.zeros(0, np.int32)
 
+    def span(self, q):
+        """[first, last+1) of query q's hits in the hit arrays"""
+        a = int(self.hit_off[q])
+        return a, a + int(self.hit_cnt[q])
+
     def positions(self, q):
         """{protein id: bool[SizeInKmer]} of query q (PositionHits, search.go:442-452)."""
-        a, b = int(self.hit_off[q]), int(self.hit_off[q + 1])
+        a, b = self.span(q)
         size = int(self.meta["size_in_kmer"][q])
         out = {}
         words = (size + 63) // 64
@@ -136,11 +143,11 @@ class BatchResult:
 
     def hits(self, q):
         """{protein id: Kmatch} of query q (the parity object: SURVEY §2.1)."""
-        a, b = int(self.hit_off[q]), int(self.hit_off[q + 1])
+        a, b = self.span(q)
         return dict(zip(self.hit_pid[a:b].tolist(), self.hit_kmatch[a:b].tolist()))
 
     def first_pos(self, q):
-        a, b = int(self.hit_off[q]), int(self.hit_off[q + 1])
+        a, b = self.span(q)
         return dict(zip(self.hit_pid[a:b].tolist(), self.hit_first_pos[a:b].tolist()))
 
 
@@ -197,13 +204,12 @@ class Index:
 class Workspace:
     """Reusable device buffers for the device-resident call."""
 
-    def __init__(self, index, max_seq_bytes, max_seqs, max_queries=0, max_hits=0, lds_slots=0,
-                 s_tier_max_kmers=0, g_tier_slots=0, seq_type=abi.PROTEIN, first_pos=0, want_positions=False,
-                 max_pos_words=0):
+    def __init__(self, index, max_seq_bytes, max_seqs, max_queries=0, max_hits=0, g_tier_slots=0, seq_type=abi.PROTEIN,
+                 first_pos=0, want_positions=False, max_pos_words=0, compact=False):
         self.index = index
         self.seq_type = seq_type
-        o = abi.WorkspaceOpts(max_seq_bytes, max_seqs, max_queries, max_hits, lds_slots, s_tier_max_kmers,
-                              g_tier_slots, seq_type, first_pos, int(want_positions), 0, max_pos_words)
+        o = abi.WorkspaceOpts(max_seq_bytes, max_seqs, max_queries, max_hits,
+                              g_tier_slots, seq_type, first_pos, int(want_positions), int(compact), max_pos_words)
         h = C.c_void_p()
         abi.check(abi.lib().kaamer_workspace_create(index._h, C.byref(o), C.byref(h)))
         self._h = h

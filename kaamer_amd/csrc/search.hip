@@ -82,11 +82,7 @@ struct alignas(16) WorkItem {
     uint64_t aa_off;  // first residue position of the query
 };
 
-#define POOL_CHUNK 256u
-// The hit pool is split into POOL_SHARDS regions, each with its own bump cursor on its own
-// cache line: one shared cursor word serialises the whole grid behind the L2 atomic unit
-// (~88 atomics/us on one address).
-#define POOL_SHARDS 64u
+#define HIT_SHARDS 64u
 #define CURSOR_STRIDE 32u  /* unsigned long long words between cursors (256 B) */
 #define MAX_TIMED_CALLS 1024u
 #define L_WAVES 8
@@ -271,8 +267,6 @@ struct CountParams {
     const uint32_t *d_nq;
     uint32_t last_group_pass;   // this launch may clear group_first behind itself
     // PositionHits pass (count_group_kernel MODE 1)
-    const uint64_t *hit_off;
-    const uint32_t *hit_pid;
     const uint64_t *pos_base;
     unsigned long long *pos_bits;
     // merge of partial hit lists (count_group_kernel MODE 2)
@@ -284,12 +278,18 @@ struct CountParams {
     uint32_t *ovf_count;
     uint32_t list_cap;
     uint32_t *queue_head;  // dynamic dequeue for the S tier
-    // per-query result location in the pool
-    uint64_t *q_start;
+    // results, written straight into their final place: hits of query q are
+    // [hit_off[q], hit_off[q] + q_cnt[q]) of the three SoA arrays.  The arrays are split into
+    // HIT_SHARDS regions, each filled from its own cursor (exact reservations, one per query
+    // group); an optional pass compacts them into CSR in query order.
+    // (An ordered single-pass layout by decoupled look-back over the groups was measured: groups
+    // then wait for every slower lower-numbered group, +30 us per batch, as much as the
+    // compaction pass it saves.)
+    uint64_t *hit_off;
     uint32_t *q_cnt;
-    uint32_t *pool_pid, *pool_km, *pool_fp;
-    uint64_t pool_shard_cap;          // entries per shard region
-    unsigned long long *pool_cursor;  // [POOL_SHARDS] cursors, CURSOR_STRIDE apart, relative to the shard base
+    uint32_t *hit_pid, *hit_km, *hit_fp;
+    uint64_t hit_shard_cap;           // entries per shard region
+    unsigned long long *hit_cursor;   // [HIT_SHARDS] cursors, CURSOR_STRIDE apart, relative to the region
     // G tier arena
     uint32_t *g_keys, *g_cnt, *g_min;
     uint64_t g_slots;
@@ -297,26 +297,16 @@ struct CountParams {
     uint32_t n_proteins;
     unsigned long long *counters;  // [CTR_REPLICAS][CTR_N]
     uint32_t *status;
-    unsigned long long *stamps;  // diagnostic build only
-    uint32_t ablate;  // timing experiments only (KAAMER_ABLATE): 1 no table adds, 2 no leftover loads, 4 no hit stores
 };
 
-// ---- diagnostic build only (-DKAAMER_STAMPS): where a counting workgroup spends its cycles.
-// The stamped build drains the memory queues at every stamp, so read its SHARES, never its
-// run time; no stamp executes in the product build.
-#ifdef KAAMER_STAMPS
-#define KSTAMP_N 10
-struct KStamps { unsigned long long acc[KSTAMP_N]; unsigned long long last; };
-#define KSTAMP_DECL KStamps kst; for (int i_ = 0; i_ < KSTAMP_N; i_++) kst.acc[i_] = 0; kst.last = wall_clock64();
-#define KSTAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long t_ = wall_clock64(); kst.acc[i] += t_ - kst.last; kst.last = t_; } while (0)
-#define KSTAMP_ARG , KStamps &kst
-#define KSTAMP_PASS , kst
-#else
-#define KSTAMP_DECL
-#define KSTAMP(i) do { } while (0)
-#define KSTAMP_ARG
-#define KSTAMP_PASS
-#endif
+// exact reservation of `total` hit entries on this workgroup's shard cursor
+__device__ __forceinline__ unsigned long long shard_alloc(const CountParams &p, uint32_t total)
+{
+    const uint32_t shard = blockIdx.x % HIT_SHARDS;
+    const unsigned long long b = atomicAdd(&p.hit_cursor[shard * CURSOR_STRIDE], (unsigned long long)total);
+    if (b + total > p.hit_shard_cap) { atomicOr(p.status, (uint32_t)ST_POOL_FULL); return ~0ull; }
+    return (unsigned long long)shard * p.hit_shard_cap + b;
+}
 
 // counting tables: protein id -> (count, lowest matching position)
 template <int LOG2CAP, bool FIRSTPOS = true> struct LdsTable {
@@ -324,13 +314,11 @@ template <int LOG2CAP, bool FIRSTPOS = true> struct LdsTable {
     uint32_t *cnt, *minpos, *nd;
     static constexpr uint32_t CAP = 1u << LOG2CAP;
     static constexpr uint32_t LIMIT = CAP - CAP / 4;  // keep 25 % free
-    uint32_t ablate;
     // n matches of `pid`, the lowest of them at `pos`.  `nnew` counts the entries this lane
     // created: the distinct-hit counter is updated once per wave, not once per insertion
     // (64 lanes bumping one LDS word serialise).
     __device__ __forceinline__ bool add_n(uint32_t pid, uint32_t pos, uint32_t n, uint32_t &nnew) const
     {
-        if (ablate & 1u) { asm volatile("" ::"v"(pid), "v"(pos), "v"(n)); return true; }
         constexpr uint32_t MASK = CAP - 1u;
         uint32_t h = (pid * 0x9E3779B1u) >> (32 - LOG2CAP);
         for (uint32_t t = 0; t <= MASK; t++) {
@@ -341,10 +329,8 @@ template <int LOG2CAP, bool FIRSTPOS = true> struct LdsTable {
                 else k = old;
             }
             if (k == pid) {
-                if (!(ablate & 8u)) {
-                    atomicAdd(&cnt[h], n);
-                    if (FIRSTPOS) atomicMin(&minpos[h], pos);
-                }
+                atomicAdd(&cnt[h], n);
+                if (FIRSTPOS) atomicMin(&minpos[h], pos);
                 return true;
             }
             h = (h + 1u) & MASK;
@@ -416,7 +402,7 @@ __device__ __forceinline__ bool add_runs(const Table &tab, uint32_t x, uint32_t 
 template <class Table, int NWIN, bool COUNT_ONLY>
 __device__ __forceinline__ bool count_windows(const CountParams &p, const uint32_t *vals,
                                               int32_t size, int32_t c0, int32_t stride, const Table &tab, PostCtr &c,
-                                              volatile uint32_t *s_pref KSTAMP_ARG)
+                                              volatile uint32_t *s_pref)
 {
     const uint32_t lane = lane_id();
     uint32_t v[NWIN];
@@ -432,7 +418,6 @@ __device__ __forceinline__ bool count_windows(const CountParams &p, const uint32
             else if (v[k] != 0u) h[k] = reinterpret_cast<const uint4 *>(p.arena)[v[k]];  // {count, id0, id1, id2}
         }
     }
-    KSTAMP(2);
     bool ok = true;
     uint32_t nnew = 0;
     // leftovers (ids beyond the three that came with the head): all their loads are issued
@@ -462,7 +447,7 @@ __device__ __forceinline__ bool count_windows(const CountParams &p, const uint32
 #pragma unroll
             for (int it = 0; it < XIT; it++) {
                 const uint32_t t = (uint32_t)it * 64u + lane;
-                const bool act = t < xtotal[k] && !(p.ablate & 2u);
+                const bool act = t < xtotal[k];
                 uint32_t lo = 0;
                 if (act) {  // largest lane with pref[lane] <= t owns leftover t
 #pragma unroll
@@ -496,7 +481,6 @@ __device__ __forceinline__ bool count_windows(const CountParams &p, const uint32
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
-    KSTAMP(3);
     // heads: inline ids and the first three ids of every list
 #pragma unroll
     for (int k = 0; k < NWIN; k++) {
@@ -521,7 +505,6 @@ __device__ __forceinline__ bool count_windows(const CountParams &p, const uint32
         const uint32_t wave_new = wave_total(nnew);
         if (lane == 0 && wave_new) atomicAdd(tab.nd, wave_new);
     }
-    KSTAMP(4);
     return __all(ok);
 }
 
@@ -547,7 +530,6 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
     unsigned long long tot_hits = 0;
     PostCtr pc;
     NullTable nt;
-    KSTAMP_DECL
     nt.nd = &s_nd;
 
     for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
@@ -560,7 +542,7 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
         // pass 1: exact number of postings (an upper bound of the distinct proteins)
         pc.clear();
         for (int32_t r0 = 0; r0 < size; r0 += 64 * WAVES * NWIN)
-            count_windows<NullTable, NWIN, true>(p, vals, size, r0 + 64 * (int32_t)wv, 64 * WAVES, nt, pc, s_pref[wv] KSTAMP_PASS);
+            count_windows<NullTable, NWIN, true>(p, vals, size, r0 + 64 * (int32_t)wv, 64 * WAVES, nt, pc, s_pref[wv]);
         {
             const unsigned long long wp = wave_total(pc.post);
             if (lane == 0 && wp) atomicAdd(&s_post, wp);
@@ -579,7 +561,7 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
         __syncthreads();
         const unsigned long long off = s_off;
         if (off == ~0ull) {
-            if (tid == 0) { p.q_cnt[q] = 0; p.q_start[q] = 0; }
+            if (tid == 0) { p.q_cnt[q] = 0; p.hit_off[q] = 0; }
             __syncthreads();
             continue;
         }
@@ -592,7 +574,7 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
         pc.clear();
         for (int32_t r0 = 0; r0 < size; r0 += 64 * WAVES * NWIN) {
             const bool ok = count_windows<GlobalTable, NWIN, false>(p, vals, size, r0 + 64 * (int32_t)wv, 64 * WAVES, gt,
-                                                                   pc, s_pref[wv] KSTAMP_PASS);
+                                                                   pc, s_pref[wv]);
             if (!ok) s_fail = 1;
         }
         __threadfence();
@@ -603,12 +585,7 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
         if (tid == 0) {
             if (failed) { atomicOr(p.status, (uint32_t)ST_G_TABLE_FULL); s_base = ~0ull; }
             else if (total == 0) s_base = 0;
-            else {
-                const uint32_t shard = blockIdx.x % POOL_SHARDS;
-                const unsigned long long b = atomicAdd(&p.pool_cursor[shard * CURSOR_STRIDE], (unsigned long long)total);
-                if (b + total > p.pool_shard_cap) { atomicOr(p.status, (uint32_t)ST_POOL_FULL); s_base = ~0ull; }
-                else s_base = (unsigned long long)shard * p.pool_shard_cap + b;
-            }
+            else s_base = shard_alloc(p, total);
         }
         __syncthreads();
         const unsigned long long base = s_base;
@@ -622,14 +599,14 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
                 wbase = __shfl(wbase, 0, 64);
                 if (has) {
                     const uint32_t idx = wbase + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull));
-                    p.pool_pid[base + idx] = k;
-                    p.pool_km[base + idx] = __hip_atomic_load(&gt.cnt[i0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    p.pool_fp[base + idx] = __hip_atomic_load(&gt.minpos[i0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    p.hit_pid[base + idx] = k;
+                    p.hit_km[base + idx] = __hip_atomic_load(&gt.cnt[i0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    p.hit_fp[base + idx] = __hip_atomic_load(&gt.minpos[i0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
             if (wv == 0) tot_hits += total;
         }
-        if (tid == 0) { p.q_cnt[q] = (base != ~0ull) ? total : 0u; p.q_start[q] = base == ~0ull ? 0 : base; }
+        if (tid == 0) { p.q_cnt[q] = (base != ~0ull) ? total : 0u; p.hit_off[q] = base == ~0ull ? 0 : base; }
         __syncthreads();
     }
     if (lane == 0) {
@@ -657,7 +634,7 @@ __device__ __forceinline__ void mark_invalid_range(unsigned long long *invalid, 
 
 __global__ void prep_protein_kernel(const uint8_t *seqs, const uint64_t *offsets, uint32_t n_seqs,
                                     kaamer_query_meta *q, uint32_t *d_nq, unsigned long long *d_n_pos,
-                                    unsigned long long *invalid, QInfo *qinfo, uint32_t *slots, uint64_t *q_start,
+                                    unsigned long long *invalid, QInfo *qinfo, uint32_t *slots, uint64_t *hit_off,
                                     uint32_t *q_cnt)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -684,7 +661,7 @@ __global__ void prep_protein_kernel(const uint8_t *seqs, const uint64_t *offsets
     m.sa_len = 0;
     q[i] = m;
     q_cnt[i] = 0;
-    q_start[i] = 0;
+    hit_off[i] = 0;
     QInfo qi;
     qi.size = size;
     qi.aa_off = b;
@@ -813,15 +790,14 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_apply_kernel(const uint32_t *
     }
 }
 
-// pool -> CSR in query order: one wave per query copies its hit list
-__global__ __launch_bounds__(256) void gather_hits_kernel(const uint32_t *d_nq, const uint64_t *hit_off,
-                                                          const uint64_t *q_start, const uint32_t *q_cnt,
-                                                          const uint32_t *pool_pid, const uint32_t *pool_km,
-                                                          const uint32_t *pool_fp, uint32_t *out_pid, uint32_t *out_km,
+// optional compaction: sharded hit arrays -> CSR in query order (one wave per query)
+__global__ __launch_bounds__(256) void gather_hits_kernel(const uint32_t *d_nq, const uint64_t *csr_off, const uint64_t *hit_off,
+                                                          const uint32_t *q_cnt, const uint32_t *in_pid, const uint32_t *in_km,
+                                                          const uint32_t *in_fp, uint32_t *out_pid, uint32_t *out_km,
                                                           uint32_t *out_fp, uint64_t out_cap, uint32_t *status, int firstpos)
 {
     const uint32_t nq = *d_nq;
-    const uint64_t n_hits = hit_off[nq];
+    const uint64_t n_hits = csr_off[nq];
     if (n_hits > out_cap) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(status, (uint32_t)ST_POOL_FULL); return; }
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -829,11 +805,11 @@ __global__ __launch_bounds__(256) void gather_hits_kernel(const uint32_t *d_nq, 
     for (uint64_t q = wave; q < nq; q += n_waves) {
         const uint32_t n = q_cnt[q];
         if (n == 0) continue;
-        const uint64_t s = q_start[q], d = hit_off[q];
+        const uint64_t s = hit_off[q], d = csr_off[q];
         for (uint32_t i = lane; i < n; i += 64) {
-            out_pid[d + i] = pool_pid[s + i];
-            out_km[d + i] = pool_km[s + i];
-            if (firstpos) out_fp[d + i] = pool_fp[s + i];
+            out_pid[d + i] = in_pid[s + i];
+            out_km[d + i] = in_km[s + i];
+            if (firstpos) out_fp[d + i] = in_fp[s + i];
         }
     }
 }
@@ -854,7 +830,7 @@ __global__ void finalize_kernel(unsigned long long *replicas, kaamer_counters *o
     if (threadIdx.x == 0) *status_out = small_state[N_LISTS + 1];
     __syncthreads();
     if (threadIdx.x < N_LISTS + 2) small_state[threadIdx.x] = 0;
-    for (uint32_t i = threadIdx.x; i <= POOL_SHARDS; i += blockDim.x) cursors[i * CURSOR_STRIDE] = 0;  // + the G arena cursor
+    for (uint32_t i = threadIdx.x; i <= HIT_SHARDS; i += blockDim.x) cursors[i * CURSOR_STRIDE] = 0;  // + the G arena cursor
 }
 
 // ------------------------------------------------------------------------------------
@@ -864,7 +840,10 @@ struct kaamer_workspace {
     int device;
     kaamer_workspace_opts opts;
     uint32_t q_cap;
-    uint64_t hit_cap, pool_cap, g_slots, pos_cap;
+    uint64_t hit_cap, sparse_cap, g_slots, pos_cap;
+    bool compact;                       // finish with CSR in query order (scan + gather pass)
+    uint64_t *d_csr_off;                // compact form: CSR offsets
+    uint32_t *d_c_pid, *d_c_km, *d_c_fp;
     int g_grid, p_grid, n_cu;
     // device buffers
     kaamer_query_meta *d_q;
@@ -872,10 +851,8 @@ struct kaamer_workspace {
     unsigned long long *d_n_pos;
     unsigned long long *d_valid;        // one bit per residue position
     uint32_t *d_vals;                   // probe result per residue position
-    uint64_t *d_q_start;
     uint32_t *d_q_cnt;
-    uint32_t *d_pool_pid, *d_pool_km, *d_pool_fp;
-    unsigned long long *d_pool_cursor;  // POOL_SHARDS pool cursors + the G arena cursor, CURSOR_STRIDE apart
+    unsigned long long *d_pool_cursor;  // HIT_SHARDS hit cursors + the G arena cursor, CURSOR_STRIDE apart
     WorkItem *d_lists;                  // [N_LISTS][q_cap] (only the G tier's overflow list is used)
     QInfo *d_qinfo;
     uint32_t *d_slots;
@@ -906,7 +883,6 @@ struct kaamer_workspace {
     uint64_t *d_pos_base;               // exclusive scan of the above
     uint64_t *d_pos_off;                // per hit: first word of its bitmap
     unsigned long long *d_pos_bits;
-    unsigned long long *d_stamps;       // diagnostic build only
     uint32_t *d_g_keys, *d_g_cnt, *d_g_min;
     unsigned long long *d_counter_replicas;
     kaamer_counters *d_counters;
@@ -1000,8 +976,8 @@ void kaamer_workspace_free(kaamer_workspace *ws)
     if (!ws) return;
     (void)hipSetDevice(ws->device);
     void *bufs[] = { ws->d_q, ws->d_nq, ws->d_n_pos, ws->d_valid, ws->d_vals, ws->d_cnt3, ws->d_off3, ws->d_n6,
-                     ws->d_tmp_meta, ws->d_orf_aa, ws->d_starts_alt, ws->d_q_start, ws->d_q_cnt, ws->d_pool_pid,
-                     ws->d_pool_km, ws->d_pool_fp, ws->d_pool_cursor, ws->d_lists, ws->d_list_counts, ws->d_status_out, ws->d_stamps, ws->d_qinfo, ws->d_slots,
+                     ws->d_tmp_meta, ws->d_orf_aa, ws->d_starts_alt, ws->d_q_cnt, ws->d_csr_off, ws->d_c_pid, ws->d_c_km, ws->d_c_fp,
+                     ws->d_pool_cursor, ws->d_lists, ws->d_list_counts, ws->d_status_out, ws->d_qinfo, ws->d_slots,
                      ws->d_slot_off, ws->d_group_first, ws->d_n_groups, ws->d_pos_words, ws->d_pos_base, ws->d_pos_off, ws->d_pos_bits, ws->d_g_keys,
                      ws->d_g_cnt, ws->d_g_min, ws->d_counter_replicas, ws->d_counters, ws->d_bsum, ws->d_bsum2, ws->d_hit_off,
                      ws->d_hit_pid, ws->d_hit_km, ws->d_hit_fp };
@@ -1066,9 +1042,6 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
         ws->groups_cap = (uint32_t)(gc > 0x7FFFFFFFull ? 0x7FFFFFFFull : gc);
     }
     int rc = KAAMER_OK;
-    // reservations are exact (one per query group); the 64 shard regions fill unevenly (+50 %)
-    ws->pool_cap = ws->hit_cap + ws->hit_cap / 2 + POOL_SHARDS * 8192ull;
-    ws->pool_cap = (ws->pool_cap + POOL_SHARDS - 1) / POOL_SHARDS * POOL_SHARDS;
     {
         uint64_t n = ws->q_cap;
         if (ws->nucleotide && (uint64_t)ws->max_seqs * 6 > n) n = (uint64_t)ws->max_seqs * 6;
@@ -1088,12 +1061,8 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
         if (!rc) rc = dev_alloc(&ws->d_orf_aa, (size_t)ws->aa_cap + 64);
         if (!rc) rc = dev_alloc(&ws->d_starts_alt, (size_t)ws->sa_cap + 64);
     }
-    if (!rc) rc = dev_alloc(&ws->d_q_start, ws->q_cap);
     if (!rc) rc = dev_alloc(&ws->d_q_cnt, ws->q_cap);
-    if (!rc) rc = dev_alloc(&ws->d_pool_pid, ws->pool_cap);
-    if (!rc) rc = dev_alloc(&ws->d_pool_km, ws->pool_cap);
-    if (!rc) rc = dev_alloc(&ws->d_pool_fp, ws->pool_cap);
-    if (!rc) rc = dev_alloc(&ws->d_pool_cursor, (size_t)(POOL_SHARDS + 1) * CURSOR_STRIDE);
+    if (!rc) rc = dev_alloc(&ws->d_pool_cursor, (size_t)(HIT_SHARDS + 1) * CURSOR_STRIDE);
     if (!rc) rc = dev_alloc(&ws->d_lists, (size_t)N_LISTS * ws->q_cap);
     if (!rc) rc = dev_alloc(&ws->d_list_counts, N_SMALL_SLOTS);
     if (!rc) rc = dev_alloc(&ws->d_status_out, 1);
@@ -1102,18 +1071,15 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     if (!rc) rc = dev_alloc(&ws->d_slot_off, (size_t)ws->q_cap + 1);
     if (!rc) rc = dev_alloc(&ws->d_group_first, ws->groups_cap);
     if (!rc) rc = dev_alloc(&ws->d_n_groups, 1);
+
     ws->want_positions = opts->want_positions != 0;
     if (!rc && ws->want_positions) {
         ws->bits_cap = opts->max_pos_words ? opts->max_pos_words : ws->hit_cap * 8;
         rc = dev_alloc(&ws->d_pos_words, ws->q_cap);
         if (!rc) rc = dev_alloc(&ws->d_pos_base, (size_t)ws->q_cap + 1);
-        if (!rc) rc = dev_alloc(&ws->d_pos_off, ws->hit_cap);
+        if (!rc) rc = dev_alloc(&ws->d_pos_off, ws->hit_cap + ws->hit_cap / 2 + HIT_SHARDS * 8192ull + HIT_SHARDS);
         if (!rc) rc = dev_alloc(&ws->d_pos_bits, ws->bits_cap);
     }
-#ifdef KAAMER_STAMPS
-    if (!rc) rc = dev_alloc(&ws->d_stamps, 64);
-    if (!rc) (void)hipMemset(ws->d_stamps, 0, 64 * sizeof(unsigned long long));
-#endif
     if (!rc) rc = dev_alloc(&ws->d_g_keys, ws->g_slots);
     if (!rc) rc = dev_alloc(&ws->d_g_cnt, ws->g_slots);
     if (!rc) rc = dev_alloc(&ws->d_g_min, ws->g_slots);
@@ -1122,10 +1088,20 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     if (!rc) rc = dev_alloc(&ws->d_bsum, ws->n_scan_blocks);
     if (!rc) rc = dev_alloc(&ws->d_bsum2, ws->n_scan_blocks);
     if (!rc) rc = dev_alloc(&ws->d_hit_off, (size_t)ws->q_cap + 1);
-    if (!rc) rc = dev_alloc(&ws->d_hit_pid, ws->hit_cap);
-    if (!rc) rc = dev_alloc(&ws->d_hit_km, ws->hit_cap);
-    if (!rc) rc = dev_alloc(&ws->d_hit_fp, ws->hit_cap);
-    if (!rc && hipMemset(ws->d_hit_fp, 0, ws->hit_cap * sizeof(uint32_t)) != hipSuccess) rc = kaamer_fail(KAAMER_E_HIP, "memset");
+    // the 64 shard regions fill unevenly (+50 %)
+    ws->sparse_cap = ((ws->hit_cap + ws->hit_cap / 2 + HIT_SHARDS * 8192ull) + HIT_SHARDS - 1) / HIT_SHARDS * HIT_SHARDS;
+    ws->compact = opts->compact != 0;
+    if (!rc) rc = dev_alloc(&ws->d_hit_pid, ws->sparse_cap);
+    if (!rc) rc = dev_alloc(&ws->d_hit_km, ws->sparse_cap);
+    if (!rc) rc = dev_alloc(&ws->d_hit_fp, ws->sparse_cap);
+    if (!rc && hipMemset(ws->d_hit_fp, 0, ws->sparse_cap * sizeof(uint32_t)) != hipSuccess) rc = kaamer_fail(KAAMER_E_HIP, "memset");
+    if (!rc && ws->compact) {
+        rc = dev_alloc(&ws->d_csr_off, (size_t)ws->q_cap + 1);
+        if (!rc) rc = dev_alloc(&ws->d_c_pid, ws->hit_cap);
+        if (!rc) rc = dev_alloc(&ws->d_c_km, ws->hit_cap);
+        if (!rc) rc = dev_alloc(&ws->d_c_fp, ws->hit_cap);
+        if (!rc && hipMemset(ws->d_c_fp, 0, ws->hit_cap * sizeof(uint32_t)) != hipSuccess) rc = kaamer_fail(KAAMER_E_HIP, "memset");
+    }
     if (rc) { kaamer_workspace_free(ws); return rc; }
     ws->ev = new (std::nothrow) std::vector<hipEvent_t>();
     if (!ws->ev) { kaamer_workspace_free(ws); return kaamer_fail(KAAMER_E_NOMEM, "event ring"); }
@@ -1137,6 +1113,34 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     }
     *out = ws;
     return KAAMER_OK;
+}
+
+// optional last step of a search / merge: CSR in query order from the sharded hit arrays
+static void launch_compaction(kaamer_workspace *ws, uint32_t nq_bound, uint32_t *status, hipStream_t s)
+{
+    if (nq_bound <= 8 * SCAN_TILE) {
+        hipLaunchKernelGGL(scan_single_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, ws->d_q_cnt, ws->d_nq, ws->d_csr_off);
+    } else {
+        const uint32_t nsb = (uint32_t)(((uint64_t)nq_bound + 1 + SCAN_TILE - 1) / SCAN_TILE);
+        hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nsb), dim3(SCAN_BLOCK), 0, s, ws->d_q_cnt, ws->d_nq, ws->d_bsum);
+        hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, ws->d_bsum, nsb);
+        hipLaunchKernelGGL(scan_apply_kernel, dim3(nsb), dim3(SCAN_BLOCK), 0, s, ws->d_q_cnt, ws->d_nq, ws->d_bsum, ws->d_csr_off);
+    }
+    uint32_t gb = (nq_bound + 3) / 4;
+    if (gb < 1) gb = 1;
+    if (gb > (uint32_t)ws->n_cu * 8) gb = (uint32_t)ws->n_cu * 8;
+    hipLaunchKernelGGL(gather_hits_kernel, dim3(gb), dim3(256), 0, s, ws->d_nq, ws->d_csr_off, ws->d_hit_off, ws->d_q_cnt, ws->d_hit_pid,
+                       ws->d_hit_km, ws->d_hit_fp, ws->d_c_pid, ws->d_c_km, ws->d_c_fp, ws->hit_cap, status, 1);
+}
+
+static void fill_result_hits(const kaamer_workspace *ws, kaamer_device_result *out)
+{
+    out->d_hit_cnt = ws->d_q_cnt;
+    out->hit_capacity = ws->compact ? ws->hit_cap : ws->sparse_cap;
+    out->d_hit_off = ws->compact ? ws->d_csr_off : ws->d_hit_off;
+    out->d_hit_pid = ws->compact ? ws->d_c_pid : ws->d_hit_pid;
+    out->d_hit_kmatch = ws->compact ? ws->d_c_km : ws->d_hit_km;
+    out->d_hit_first_pos = ws->compact ? ws->d_c_fp : ws->d_hit_fp;
 }
 
 int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *d_seqs, const uint64_t *d_offsets,
@@ -1162,7 +1166,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     HIPCHK(hipEventRecord(ev[0], s));
     if (!ws->clean) {
         // first batch, or a previous batch did not run to its finalize kernel
-        HIPCHK(hipMemsetAsync(ws->d_pool_cursor, 0, (size_t)(POOL_SHARDS + 1) * CURSOR_STRIDE * sizeof(unsigned long long), s));
+        HIPCHK(hipMemsetAsync(ws->d_pool_cursor, 0, (size_t)(HIT_SHARDS + 1) * CURSOR_STRIDE * sizeof(unsigned long long), s));
         HIPCHK(hipMemsetAsync(ws->d_list_counts, 0, N_SMALL_SLOTS * sizeof(uint32_t), s));
         HIPCHK(hipMemsetAsync(ws->d_counter_replicas, 0, sizeof(unsigned long long) * CTR_REPLICAS * CTR_N, s));
         HIPCHK(hipMemsetAsync(ws->d_valid, 0, (size_t)(ws->pos_cap / 64 + 2) * sizeof(unsigned long long), s));
@@ -1180,7 +1184,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     if (!nucl) {
         hipLaunchKernelGGL(prep_protein_kernel, dim3((n_seqs + pb - 1) / pb > 0 ? (n_seqs + pb - 1) / pb : 1), dim3(pb), 0, s,
                            d_seqs, d_offsets, n_seqs, ws->d_q, ws->d_nq, ws->d_n_pos, ws->d_valid, ws->d_qinfo, ws->d_slots,
-                           ws->d_q_start, ws->d_q_cnt);
+                           ws->d_hit_off, ws->d_q_cnt);
     } else {
         // 6-frame translation: count, scan, write, order (translate.hip.inc)
         const size_t n6 = (size_t)n_seqs * 6, cap6 = (size_t)ws->max_seqs * 6;
@@ -1211,7 +1215,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         hipLaunchKernelGGL(orf_order_kernel, dim3(ws->n_cu * 4), dim3(256), 0, s, ws->d_tmp_meta, tp.off_orf, n_seqs, ws->d_q,
                            ws->d_nq, ws->d_n_pos, tp.off_aa, (uint64_t)ws->q_cap, status);
         hipLaunchKernelGGL(prep_orf_kernel, dim3(ws->n_cu * 4), dim3(pb), 0, s, ws->d_q, ws->d_nq, ws->d_valid, ws->d_n_pos,
-                           ws->d_qinfo, ws->d_slots, ws->d_q_start, ws->d_q_cnt);
+                           ws->d_qinfo, ws->d_slots, ws->d_hit_off, ws->d_q_cnt);
         residues = ws->d_orf_aa;
         pos_bound = ws->aa_cap;
         nq_bound = ws->q_cap;
@@ -1269,23 +1273,21 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     p.d_nq = ws->d_nq;
     p.list_cap = ws->q_cap;
     p.queue_head = queue_head;
-    p.q_start = ws->d_q_start;
+    p.hit_off = ws->d_hit_off;
     p.q_cnt = ws->d_q_cnt;
-    p.pool_pid = ws->d_pool_pid;
-    p.pool_km = ws->d_pool_km;
-    p.pool_fp = ws->d_pool_fp;
-    p.pool_shard_cap = ws->pool_cap / POOL_SHARDS;
-    p.pool_cursor = ws->d_pool_cursor;
+    p.hit_pid = ws->d_hit_pid;
+    p.hit_km = ws->d_hit_km;
+    p.hit_fp = ws->d_hit_fp;
+    p.hit_shard_cap = ws->sparse_cap / HIT_SHARDS;
+    p.hit_cursor = ws->d_pool_cursor;
     p.g_keys = ws->d_g_keys;
     p.g_cnt = ws->d_g_cnt;
     p.g_min = ws->d_g_min;
     p.g_slots = ws->g_slots;
-    p.g_cursor = ws->d_pool_cursor + (size_t)POOL_SHARDS * CURSOR_STRIDE;
+    p.g_cursor = ws->d_pool_cursor + (size_t)HIT_SHARDS * CURSOR_STRIDE;
     p.n_proteins = ix->hdr.max_protein_id + 1u ? ix->hdr.max_protein_id + 1u : 0xFFFFFFFFu;
     p.counters = ws->d_counter_replicas;
     p.status = status;
-    p.stamps = ws->d_stamps;
-    if (const char *e = getenv("KAAMER_ABLATE")) p.ablate = (uint32_t)atoi(e);
     auto list_ptr = [&](int which) { return ws->d_lists + (size_t)which * ws->q_cap; };
 
     if (!small_prep) HIPCHK(hipStreamWaitEvent(s, ws->ev_join, 0));
@@ -1305,24 +1307,9 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     int g_grid = ws->g_grid;
     if ((uint32_t)g_grid > nq_bound) g_grid = nq_bound > 0 ? (int)nq_bound : 1;
     hipLaunchKernelGGL(count_global_kernel, dim3(g_grid), dim3(64 * G_WAVES), 0, s, pg);
+    if (ws->compact) launch_compaction(ws, nq_bound, status, s);
     HIPCHK(hipEventRecord(ev[3], s));
 
-    if (nq_bound <= 8 * SCAN_TILE) {
-        hipLaunchKernelGGL(scan_single_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, ws->d_q_cnt, ws->d_nq, ws->d_hit_off);
-    } else {
-        const uint32_t nsb = (uint32_t)(((uint64_t)nq_bound + 1 + SCAN_TILE - 1) / SCAN_TILE);
-        hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nsb), dim3(SCAN_BLOCK), 0, s, ws->d_q_cnt, ws->d_nq, ws->d_bsum);
-        hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, ws->d_bsum, nsb);
-        hipLaunchKernelGGL(scan_apply_kernel, dim3(nsb), dim3(SCAN_BLOCK), 0, s, ws->d_q_cnt, ws->d_nq, ws->d_bsum, ws->d_hit_off);
-    }
-    {
-        uint32_t gb = (nq_bound + 3) / 4;  // 4 waves per block, one query per wave
-        if (gb < 1) gb = 1;
-        if (gb > (uint32_t)ws->n_cu * 64) gb = (uint32_t)ws->n_cu * 64;
-        hipLaunchKernelGGL(gather_hits_kernel, dim3(gb), dim3(256), 0, s, ws->d_nq, ws->d_hit_off, ws->d_q_start, ws->d_q_cnt,
-                           ws->d_pool_pid, ws->d_pool_km, ws->d_pool_fp, ws->d_hit_pid, ws->d_hit_km, ws->d_hit_fp,
-                           ws->hit_cap, status, ws->firstpos ? 1 : 0);
-    }
     if (ws->want_positions) {
         // PositionHits bitmaps (search.go:442-452): layout from the final hit lists, then one more
         // pass of the group kernel that sets one bit per (hit, position)
@@ -1338,12 +1325,11 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
             hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, ws->d_bsum, nsb);
             hipLaunchKernelGGL(scan_apply_kernel, dim3(nsb), dim3(SCAN_BLOCK), 0, s, ws->d_pos_words, ws->d_nq, ws->d_bsum, ws->d_pos_base);
         }
-        hipLaunchKernelGGL(pos_layout_kernel, dim3(ws->n_cu * 8), dim3(256), 0, s, ws->d_qinfo, ws->d_q_cnt, ws->d_hit_off,
+        hipLaunchKernelGGL(pos_layout_kernel, dim3(ws->n_cu * 8), dim3(256), 0, s, ws->d_qinfo, ws->d_q_cnt,
+                           ws->compact ? ws->d_csr_off : ws->d_hit_off,
                            ws->d_pos_base, ws->d_nq, ws->d_pos_off, ws->d_pos_bits, ws->bits_cap, status);
         CountParams pp2 = p;
         pp2.last_group_pass = 1u;
-        pp2.hit_off = ws->d_hit_off;
-        pp2.hit_pid = ws->d_hit_pid;
         pp2.pos_base = ws->d_pos_base;
         pp2.pos_bits = ws->d_pos_bits;
         pp2.ovf_list = list_ptr(LIST_SO); pp2.ovf_count = ws->d_list_counts + LIST_SO;
@@ -1360,10 +1346,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     out->n_queries_cap = ws->q_cap;
     out->d_n_queries = ws->d_nq;
     out->d_q = ws->d_q;
-    out->d_hit_off = ws->d_hit_off;
-    out->d_hit_pid = ws->d_hit_pid;
-    out->d_hit_kmatch = ws->d_hit_km;
-    out->d_hit_first_pos = ws->d_hit_fp;
+    fill_result_hits(ws, out);
     out->d_orf_aa = nucl ? ws->d_orf_aa : nullptr;
     out->d_starts_alt = nucl ? ws->d_starts_alt : nullptr;
     out->d_counters = ws->d_counters;
@@ -1383,7 +1366,7 @@ int kaamer_merge_device(kaamer_workspace *ws, const uint64_t *d_ent_off, const u
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(ws->device));
     if (!ws->clean) {
-        HIPCHK(hipMemsetAsync(ws->d_pool_cursor, 0, (size_t)(POOL_SHARDS + 1) * CURSOR_STRIDE * sizeof(unsigned long long), s));
+        HIPCHK(hipMemsetAsync(ws->d_pool_cursor, 0, (size_t)(HIT_SHARDS + 1) * CURSOR_STRIDE * sizeof(unsigned long long), s));
         HIPCHK(hipMemsetAsync(ws->d_list_counts, 0, N_SMALL_SLOTS * sizeof(uint32_t), s));
         HIPCHK(hipMemsetAsync(ws->d_counter_replicas, 0, sizeof(unsigned long long) * CTR_REPLICAS * CTR_N, s));
         HIPCHK(hipMemsetAsync(ws->d_valid, 0, (size_t)(ws->pos_cap / 64 + 2) * sizeof(unsigned long long), s));
@@ -1394,7 +1377,7 @@ int kaamer_merge_device(kaamer_workspace *ws, const uint64_t *d_ent_off, const u
     const uint32_t nq_bound = n_queries;
     const int pb = 256;
     hipLaunchKernelGGL(prep_merge_kernel, dim3((n_queries + pb - 1) / pb > 0 ? (n_queries + pb - 1) / pb : 1), dim3(pb), 0, s, d_ent_off,
-                       n_queries, ws->d_qinfo, ws->d_slots, ws->d_nq, ws->d_q_start, ws->d_q_cnt);
+                       n_queries, ws->d_qinfo, ws->d_slots, ws->d_nq, ws->d_hit_off, ws->d_q_cnt);
     if (nq_bound <= 8 * SCAN_TILE) {
         hipLaunchKernelGGL(scan_single_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, ws->d_slots, ws->d_nq, ws->d_slot_off);
     } else {
@@ -1420,14 +1403,14 @@ int kaamer_merge_device(kaamer_workspace *ws, const uint64_t *d_ent_off, const u
     p.last_group_pass = 1u;
     p.m_pid = d_pid; p.m_km = d_km; p.m_fp = d_fp;
     p.list_cap = ws->q_cap;
-    p.q_start = ws->d_q_start;
+    p.hit_off = ws->d_hit_off;
     p.q_cnt = ws->d_q_cnt;
-    p.pool_pid = ws->d_pool_pid; p.pool_km = ws->d_pool_km; p.pool_fp = ws->d_pool_fp;
-    p.pool_shard_cap = ws->pool_cap / POOL_SHARDS;
-    p.pool_cursor = ws->d_pool_cursor;
+    p.hit_pid = ws->d_hit_pid; p.hit_km = ws->d_hit_km; p.hit_fp = ws->d_hit_fp;
+    p.hit_shard_cap = ws->sparse_cap / HIT_SHARDS;
+    p.hit_cursor = ws->d_pool_cursor;
     p.g_keys = ws->d_g_keys; p.g_cnt = ws->d_g_cnt; p.g_min = ws->d_g_min;
     p.g_slots = ws->g_slots;
-    p.g_cursor = ws->d_pool_cursor + (size_t)POOL_SHARDS * CURSOR_STRIDE;
+    p.g_cursor = ws->d_pool_cursor + (size_t)HIT_SHARDS * CURSOR_STRIDE;
     p.counters = ws->d_counter_replicas;
     p.status = status;
     auto list_ptr = [&](int which) { return ws->d_lists + (size_t)which * ws->q_cap; };
@@ -1442,22 +1425,7 @@ int kaamer_merge_device(kaamer_workspace *ws, const uint64_t *d_ent_off, const u
     int g_grid = ws->g_grid;
     if ((uint32_t)g_grid > nq_bound) g_grid = nq_bound > 0 ? (int)nq_bound : 1;
     hipLaunchKernelGGL(merge_global_kernel, dim3(g_grid), dim3(256), 0, s, pg);
-    if (nq_bound <= 8 * SCAN_TILE) {
-        hipLaunchKernelGGL(scan_single_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, ws->d_q_cnt, ws->d_nq, ws->d_hit_off);
-    } else {
-        const uint32_t nsb = (uint32_t)(((uint64_t)nq_bound + 1 + SCAN_TILE - 1) / SCAN_TILE);
-        hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nsb), dim3(SCAN_BLOCK), 0, s, ws->d_q_cnt, ws->d_nq, ws->d_bsum);
-        hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, ws->d_bsum, nsb);
-        hipLaunchKernelGGL(scan_apply_kernel, dim3(nsb), dim3(SCAN_BLOCK), 0, s, ws->d_q_cnt, ws->d_nq, ws->d_bsum, ws->d_hit_off);
-    }
-    {
-        uint32_t gb = (nq_bound + 3) / 4;
-        if (gb < 1) gb = 1;
-        if (gb > (uint32_t)ws->n_cu * 64) gb = (uint32_t)ws->n_cu * 64;
-        hipLaunchKernelGGL(gather_hits_kernel, dim3(gb), dim3(256), 0, s, ws->d_nq, ws->d_hit_off, ws->d_q_start, ws->d_q_cnt,
-                           ws->d_pool_pid, ws->d_pool_km, ws->d_pool_fp, ws->d_hit_pid, ws->d_hit_km, ws->d_hit_fp,
-                           ws->hit_cap, status, 1);
-    }
+    if (ws->compact) launch_compaction(ws, nq_bound, status, s);
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, s, ws->d_counter_replicas, ws->d_counters, ws->d_list_counts,
                        ws->d_status_out, ws->d_pool_cursor);
     HIPCHK(hipGetLastError());
@@ -1465,10 +1433,7 @@ int kaamer_merge_device(kaamer_workspace *ws, const uint64_t *d_ent_off, const u
     memset(out, 0, sizeof *out);
     out->n_queries_cap = ws->q_cap;
     out->d_n_queries = ws->d_nq;
-    out->d_hit_off = ws->d_hit_off;
-    out->d_hit_pid = ws->d_hit_pid;
-    out->d_hit_kmatch = ws->d_hit_km;
-    out->d_hit_first_pos = ws->d_hit_fp;
+    fill_result_hits(ws, out);
     out->d_counters = ws->d_counters;
     return KAAMER_OK;
 }
@@ -1483,21 +1448,6 @@ int kaamer_workspace_finish(kaamer_workspace *ws, void *stream, kaamer_counters 
     kaamer_counters c;
     HIPCHK(hipMemcpy(&c, ws->d_counters, sizeof c, hipMemcpyDeviceToHost));
     if (out) *out = c;
-#ifdef KAAMER_STAMPS
-    {
-        unsigned long long st[64];
-        HIPCHK(hipMemcpy(st, ws->d_stamps, sizeof st, hipMemcpyDeviceToHost));
-        static const char *names[KSTAMP_N] = { "desc", "clear", "load v/h", "leftovers", "adds", "barrier", "compact", "next", "-", "loop" };
-        for (int t = 0; t < 2; t++) {
-            unsigned long long tot = 0;
-            for (int i = 0; i < KSTAMP_N; i++) tot += st[t * KSTAMP_N + i];
-            fprintf(stderr, "[stamps] %s tier (100 MHz ticks summed over workgroups, all batches):", t ? "L" : "S");
-            for (int i = 0; i < KSTAMP_N; i++)
-                if (st[t * KSTAMP_N + i]) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * (double)st[t * KSTAMP_N + i] / (double)(tot ? tot : 1));
-            fprintf(stderr, "  total %llu\n", tot);
-        }
-    }
-#endif
     if (status) ws->clean = false;  // an aborted batch may leave per-batch state behind
     if (status & ST_POOL_FULL) return kaamer_fail(KAAMER_E_CAPACITY, "hit pool exhausted: raise workspace max_hits (now %llu)", (unsigned long long)ws->hit_cap);
     if (status & ST_LIST_FULL) return kaamer_fail(KAAMER_E_CAPACITY, "tier work list exhausted");
@@ -1547,6 +1497,7 @@ struct batch_out_owner {
     kaamer_batch_out pub;
     std::vector<kaamer_query_meta> q;
     std::vector<uint64_t> hit_off;
+    std::vector<uint32_t> hit_cnt;
     std::vector<uint32_t> pid, km, fp;
     std::vector<uint8_t> orf_aa;
     std::vector<int32_t> starts_alt;
@@ -1566,6 +1517,7 @@ static int search_batch_once(kaamer_index *ix, const kaamer_batch_in *in, uint64
     o.seq_type = in->seq_type;
     o.first_pos = 1;  // kaamer_batch_out always carries hit_first_pos
     o.want_positions = in->want_positions ? 1u : 0u;
+    o.compact = 1u;  // the host form is CSR
     o.max_pos_words = max_hits * 8;
     o.max_queries = max_queries;
     kaamer_workspace *ws = nullptr;
@@ -1593,7 +1545,8 @@ static int search_batch_once(kaamer_index *ix, const kaamer_batch_in *in, uint64
     bo = new (std::nothrow) batch_out_owner();
     if (!bo) { rc = kaamer_fail(KAAMER_E_NOMEM, "batch_out"); goto done; }
     e = hipMemcpy(&nq, dr.d_n_queries, 4, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) { bo->q.resize(nq); bo->hit_off.resize((size_t)nq + 1); }
+    if (e == hipSuccess) { bo->q.resize(nq); bo->hit_off.resize((size_t)nq + 1); bo->hit_cnt.resize((size_t)nq + 1); }
+    if (e == hipSuccess && nq) e = hipMemcpy(bo->hit_cnt.data(), dr.d_hit_cnt, (size_t)nq * 4, hipMemcpyDeviceToHost);
     if (e == hipSuccess && nq) e = hipMemcpy(bo->q.data(), dr.d_q, (size_t)nq * sizeof(kaamer_query_meta), hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipMemcpy(bo->hit_off.data(), dr.d_hit_off, ((size_t)nq + 1) * 8, hipMemcpyDeviceToHost);
     if (e == hipSuccess) {
@@ -1627,6 +1580,7 @@ static int search_batch_once(kaamer_index *ix, const kaamer_batch_in *in, uint64
     bo->pub.n_queries = nq;
     bo->pub.q = bo->q.data();
     bo->pub.hit_off = bo->hit_off.data();
+    bo->pub.hit_cnt = bo->hit_cnt.data();
     bo->pub.hit_pid = bo->pid.data();
     bo->pub.hit_kmatch = bo->km.data();
     bo->pub.hit_first_pos = bo->fp.data();

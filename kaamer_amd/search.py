@@ -25,7 +25,7 @@ class SearchOptions:  # search.go:56-71 (the fields the hot path reads); default
 
 def _sorted_hits(res, q):
     """sortMapByValue (search.go:132-152): Kmatch descending (ties by protein id)"""
-    a, b = int(res.hit_off[q]), int(res.hit_off[q + 1])
+    a, b = res.span(q)
     pid = np.ascontiguousarray(res.hit_pid[a:b])
     km = np.ascontiguousarray(res.hit_kmatch[a:b])
     order = np.zeros(b - a, dtype=np.uint32)

@@ -36,18 +36,18 @@ def _ranges_index(starts, counts):
     return torch.repeat_interleave(starts - dst, counts) + torch.arange(total, device=starts.device)
 
 
-def build_send(hit_off, pid, km, fp, world):
-    """partial CSR of ALL queries -> buffers ordered by destination rank.
+def build_send(hit_off, hit_cnt, pid, km, fp, world):
+    """partial hit lists of ALL queries (first hit, count per query) -> buffers ordered by destination rank.
 
     returns (cnt_p [nq] int64: per-query counts in owner order,
              ents [n, 3] int32-like: the entries in the same order,
              q_splits, e_splits: per-destination numbers of queries / entries)"""
-    nq = hit_off.numel() - 1
+    nq = hit_cnt.numel()
     dev = hit_off.device
-    cnt = (hit_off[1:] - hit_off[:-1]).to(torch.int64)
+    cnt = hit_cnt.to(torch.int64)
     perm = owner_perm(nq, world, dev)
     cnt_p = cnt[perm]
-    idx = _ranges_index(hit_off[:-1].to(torch.int64)[perm], cnt_p)
+    idx = _ranges_index(hit_off[:nq].to(torch.int64)[perm], cnt_p)
     ents = torch.stack([pid[idx], km[idx], fp[idx]], dim=1) if idx.numel() else \
         torch.zeros((0, 3), dtype=pid.dtype, device=dev)
     q_splits = [n_owned(nq, world, d) for d in range(world)]
@@ -115,12 +115,13 @@ class ShardedSearcher:
         """-> (ent_off, merged DeviceResult, counters of the local search)"""
         r = self.ws.search_device(d_buf.data_ptr(), d_off.data_ptr(), n_seqs, seq_bytes, stream=stream)
         c = self.ws.finish(stream)
-        n_hits = c["n_hits"]
-        hit_off = dev_tensor(r.d_hit_off, n_seqs + 1, torch.int64)
-        pid = dev_tensor(r.d_hit_pid, n_hits, torch.int32)
-        km = dev_tensor(r.d_hit_kmatch, n_hits, torch.int32)
-        fp = dev_tensor(r.d_hit_first_pos, n_hits, torch.int32)
-        cnt_p, ents, qs, es = build_send(hit_off, pid, km, fp, self.world)
+        cap = int(r.hit_capacity)  # the lists sit where the counting kernel put them (hit_off, hit_cnt)
+        hit_off = dev_tensor(r.d_hit_off, n_seqs, torch.int64)
+        hit_cnt = dev_tensor(r.d_hit_cnt, n_seqs, torch.int32)
+        pid = dev_tensor(r.d_hit_pid, cap, torch.int32)
+        km = dev_tensor(r.d_hit_kmatch, cap, torch.int32)
+        fp = dev_tensor(r.d_hit_first_pos, cap, torch.int32)
+        cnt_p, ents, qs, es = build_send(hit_off, hit_cnt, pid, km, fp, self.world)
         recv_cnt, recv_ents = exchange(cnt_p, ents, qs, es, self.rank, self.world, self.group)
         ent_off, q_ents = to_query_major(recv_cnt, recv_ents)
         cols = [q_ents[:, i].contiguous() for i in range(3)] if q_ents.numel() else \

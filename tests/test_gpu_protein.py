@@ -153,12 +153,15 @@ def _device_search(ix, seqs, **ws_opts):
     r = ws.search_device(d_buf.data_ptr(), d_off.data_ptr(), len(seqs), len(buf), stream=st)
     c = ws.finish(st)
     hit_off = _from_ptr(r.d_hit_off, len(seqs) + 1, np.uint64)
-    n = int(hit_off[-1])
+    hit_cnt = _from_ptr(r.d_hit_cnt, len(seqs), np.uint32)
+    n = int(r.hit_capacity)
+    if ws_opts.get("compact"):  # CSR in query order
+        assert hit_off[0] == 0 and (np.diff(hit_off.astype(np.int64)) == hit_cnt).all()
+        assert int(hit_off[-1]) == c["n_hits"]
     pid, km, fp = (_from_ptr(x, n, np.uint32) for x in (r.d_hit_pid, r.d_hit_kmatch, r.d_hit_first_pos))
-    hits = [dict(zip(pid[int(hit_off[i]):int(hit_off[i + 1])].tolist(), km[int(hit_off[i]):int(hit_off[i + 1])].tolist()))
-            for i in range(len(seqs))]
-    first = [dict(zip(pid[int(hit_off[i]):int(hit_off[i + 1])].tolist(), fp[int(hit_off[i]):int(hit_off[i + 1])].tolist()))
-             for i in range(len(seqs))]
+    sp = [(int(hit_off[i]), int(hit_off[i]) + int(hit_cnt[i])) for i in range(len(seqs))]
+    hits = [dict(zip(pid[a:b].tolist(), km[a:b].tolist())) for a, b in sp]
+    first = [dict(zip(pid[a:b].tolist(), fp[a:b].tolist())) for a, b in sp]
     return hits, first, c
 
 
@@ -179,8 +182,7 @@ def test_tier_escalation_is_exact(klib, oracle, gpu_device):
     seqs = [core, long_q, db[7], core[:20], b"ACDEFGHIKLMNPQRSTVWY"]
     exp = _oracle_hits(oix, oracle, seqs)
     assert len(exp[0][0]) == 5000
-    for opts in (dict(), dict(lds_slots=64), dict(lds_slots=2048), dict(s_tier_max_kmers=16),
-                 dict(s_tier_max_kmers=100000)):
+    for opts in (dict(), dict(compact=True), dict(g_tier_slots=1 << 20)):
         hits, first, c = _device_search(ix, seqs, **opts)
         for i, (h, f) in enumerate(exp):
             assert hits[i] == h and first[i] == f, (opts, i)
@@ -203,8 +205,8 @@ def test_device_resident_call_and_reuse(small, oracle):
     from kaamer_amd import api, workload
     db, img, ix, oix = small
     stream = torch.cuda.Stream()
-    ws = api.Workspace(ix, 1 << 20, 500)
     for seed in (1, 2, 3):
+        ws = api.Workspace(ix, 1 << 20, 500, compact=(seed == 2))
         q = workload.make_protein_queries(db, 300, seed=seed)
         buf, offs = q
         with torch.cuda.stream(stream):
@@ -218,10 +220,14 @@ def test_device_resident_call_and_reuse(small, oracle):
 
         # read results back through torch from the raw device pointers
         hit_off = _from_ptr(r.d_hit_off, 301, np.uint64)
-        pid = _from_ptr(r.d_hit_pid, n_hits, np.uint32)
-        km = _from_ptr(r.d_hit_kmatch, n_hits, np.uint32)
+        hit_cnt = _from_ptr(r.d_hit_cnt, 300, np.uint32)
+        assert int(hit_cnt.sum()) == n_hits
+        if seed == 2:
+            assert int(hit_off[300]) == n_hits
+        pid = _from_ptr(r.d_hit_pid, int(r.hit_capacity), np.uint32)
+        km = _from_ptr(r.d_hit_kmatch, int(r.hit_capacity), np.uint32)
         for qi, (hits, _) in enumerate(exp):
-            a, b = int(hit_off[qi]), int(hit_off[qi + 1])
+            a, b = int(hit_off[qi]), int(hit_off[qi]) + int(hit_cnt[qi])
             assert dict(zip(pid[a:b].tolist(), km[a:b].tolist())) == hits
         t = ws.kernel_ms_sum()
         assert 0 < t["probe_ms"] and 0 < t["count_ms"] and t["probe_ms"] + t["count_ms"] <= t["total_ms"]

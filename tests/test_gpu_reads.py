@@ -134,13 +134,14 @@ def test_reads_device_call_reuse(small, oracle):
         nq = int(_from_ptr(r.d_n_queries, 1, np.uint32)[0])
         assert nq == sum(len(e) for e in exp_orfs) == c["n_queries"]
         hit_off = _from_ptr(r.d_hit_off, nq + 1, np.uint64)
-        pid = _from_ptr(r.d_hit_pid, int(hit_off[-1]), np.uint32)
-        km = _from_ptr(r.d_hit_kmatch, int(hit_off[-1]), np.uint32)
+        hit_cnt = _from_ptr(r.d_hit_cnt, nq, np.uint32)
+        pid = _from_ptr(r.d_hit_pid, int(r.hit_capacity), np.uint32)
+        km = _from_ptr(r.d_hit_kmatch, int(r.hit_capacity), np.uint32)
         q = 0
         for e in exp_orfs:
             for o in e:
                 p, k, _ = oix.search(o["seq"])
-                a, b = int(hit_off[q]), int(hit_off[q + 1])
+                a, b = int(hit_off[q]), int(hit_off[q]) + int(hit_cnt[q])
                 assert dict(zip(pid[a:b].tolist(), km[a:b].tolist())) == dict(zip(p.tolist(), k.tolist()))
                 q += 1
 

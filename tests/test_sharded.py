@@ -57,7 +57,7 @@ def _gloo_worker(rank, world, port, ret):
         k, i = _shard_pairs(klib, O, db, rank, world)
         oix = O.Index.from_pairs(k, i)
         off, pid, km, fp = (torch.from_numpy(x) for x in _partial_csr(O, oix, seqs))
-        cnt_p, ents, qs, es = sharded.build_send(off, pid, km, fp, world)
+        cnt_p, ents, qs, es = sharded.build_send(off, (off[1:] - off[:-1]).to(torch.int32), pid, km, fp, world)
         recv_cnt, recv_ents = sharded.exchange(cnt_p, ents, qs, es, rank, world)
         ent_off, q_ents = sharded.to_query_major(recv_cnt, recv_ents)
         merged = _numpy_merge(ent_off.numpy(), q_ents.numpy())
@@ -104,7 +104,7 @@ def test_exchange_helpers_single_process():
     pid = torch.arange(n, dtype=torch.int32) * 7
     km = torch.arange(n, dtype=torch.int32) + 1
     fp = torch.arange(n, dtype=torch.int32) % 5
-    cnt_p, ents, qs, es = sharded.build_send(off, pid, km, fp, world)
+    cnt_p, ents, qs, es = sharded.build_send(off, torch.from_numpy(cnt.astype(np.int32)), pid, km, fp, world)
     assert qs == [6, 6, 5] and sum(es) == n and cnt_p.tolist() == [int(cnt[q]) for d in range(world) for q in range(d, nq, world)]
     # destination 1 receives, from this single source, the lists of queries 1, 4, 7, ...
     qb, eb = np.cumsum([0] + qs), np.cumsum([0] + es)
@@ -137,9 +137,10 @@ def test_two_shards_merge_on_one_gpu(klib, oracle, gpu_device):
         res = ws.search_device(d_buf.data_ptr(), d_off.data_ptr(), n_seqs, len(buf), stream=st)
         c = ws.finish(st)
         total_lookups += c["n_lookup"]
-        nh = c["n_hits"]
-        hit_off = sharded.dev_tensor(res.d_hit_off, n_seqs + 1, torch.int64)
-        sends.append(sharded.build_send(hit_off, sharded.dev_tensor(res.d_hit_pid, nh, torch.int32),
+        nh = int(res.hit_capacity)
+        hit_off = sharded.dev_tensor(res.d_hit_off, n_seqs, torch.int64)
+        sends.append(sharded.build_send(hit_off, sharded.dev_tensor(res.d_hit_cnt, n_seqs, torch.int32),
+                                        sharded.dev_tensor(res.d_hit_pid, nh, torch.int32),
                                         sharded.dev_tensor(res.d_hit_kmatch, nh, torch.int32),
                                         sharded.dev_tensor(res.d_hit_first_pos, nh, torch.int32), world))
         keep.append((ix, ws))
@@ -160,9 +161,10 @@ def test_two_shards_merge_on_one_gpu(klib, oracle, gpu_device):
                              ent_off.numel() - 1, int(q_ents.shape[0]), stream=st)
         c = mws.finish(st)
         owned = list(range(d, n_seqs, world))
-        hit_off = sharded.dev_tensor(m.d_hit_off, len(owned) + 1, torch.int64).cpu().numpy()
-        nh = int(hit_off[-1])
-        assert nh == c["n_hits"]
+        hit_off = sharded.dev_tensor(m.d_hit_off, len(owned), torch.int64).cpu().numpy()
+        hit_cnt = sharded.dev_tensor(m.d_hit_cnt, len(owned), torch.int32).cpu().numpy()
+        nh = int(m.hit_capacity)
+        assert int(hit_cnt.sum()) == c["n_hits"]
         pid = sharded.dev_tensor(m.d_hit_pid, nh, torch.int32).cpu().numpy().view(np.uint32)
         km = sharded.dev_tensor(m.d_hit_kmatch, nh, torch.int32).cpu().numpy()
         fp = sharded.dev_tensor(m.d_hit_first_pos, nh, torch.int32).cpu().numpy()
@@ -171,6 +173,6 @@ def test_two_shards_merge_on_one_gpu(klib, oracle, gpu_device):
             if oracle.size_in_kmer(seqs[q]) >= 7:
                 p, k, pos = full.search(seqs[q], want_positions=True)
                 exp = {int(a): (int(b), int(np.argmax(pos[i]))) for i, (a, b) in enumerate(zip(p, k))}
-            a, b = int(hit_off[j]), int(hit_off[j + 1])
+            a, b = int(hit_off[j]), int(hit_off[j]) + int(hit_cnt[j])
             got = {int(x): (int(y), int(z)) for x, y, z in zip(pid[a:b], km[a:b], fp[a:b])}
             assert got == exp, (d, q)
