@@ -98,6 +98,8 @@ def main():
                     help="N>1: replicas = every rank holds the table and its own batch (default; the DB fits one GPU); "
                          "sharded = the table is split by hash prefix, all ranks search one common batch, partial hit "
                          "lists are exchanged with one RCCL all-to-all and merged by the query's owner")
+    ap.add_argument("--time-every", type=int, default=8,
+                    help="bracket the kernels of every k-th timed step with HIP events (roofline.achieved is their average)")
     ap.add_argument("--compact", type=int, default=0,
                     help="1: finish every batch with the hit lists packed in query order (one more scan + copy pass); "
                          "0 (default): each query's list stays where the counting kernel wrote it (offset + count per query)")
@@ -167,6 +169,7 @@ def main():
     for _ in range(args.warmup):
         step()
     counters = (mws if sharded_mode else ws).finish(stream)  # also validates the batch (capacity / overflow)
+    ws.set_timing(args.time_every)  # sampled: an event record idles the stream for a few microseconds
     ws.reset_timers()
 
     if world > 1:

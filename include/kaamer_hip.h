@@ -243,9 +243,12 @@ int kaamer_merge_device(kaamer_workspace *ws, const uint64_t *d_ent_off, const u
 /* Waits for `stream`, copies the counters to the host and reports a deferred
  * KAAMER_E_CAPACITY if a device-side bound was exceeded during the batch. */
 int kaamer_workspace_finish(kaamer_workspace *ws, void *stream, kaamer_counters *out);
-/* HIP-event times (ms), measured on the stream the kernels were launched on and
- * summed over the kaamer_search_device calls made on this workspace since the
- * previous kaamer_workspace_reset_timers (at most 1024 calls are kept):
+/* Kernel timers.  kaamer_workspace_set_timing(ws, k): k = 0 (default) records no
+ * events; k >= 1 brackets the kernels of every k-th kaamer_search_device call with
+ * HIP events on the caller's stream (each record idles the stream for a few
+ * microseconds, hence the sampling).  kaamer_workspace_kernel_ms_sum returns the
+ * times (ms) summed over the n_calls sampled calls since the previous
+ * kaamer_workspace_reset_timers (at most 1024 are kept):
  *   probe_ms  the probe kernel (the dominant kernel: one 64-B bucket per lookup)
  *   count_ms  the counting tiers (postings expansion + per-protein counting)
  *   total_ms  the whole batch, prep to CSR
@@ -253,6 +256,7 @@ int kaamer_workspace_finish(kaamer_workspace *ws, void *stream, kaamer_counters 
 int kaamer_workspace_kernel_ms_sum(kaamer_workspace *ws, double *probe_ms, double *count_ms,
                                    double *total_ms, uint32_t *n_calls);
 void kaamer_workspace_reset_timers(kaamer_workspace *ws);
+void kaamer_workspace_set_timing(kaamer_workspace *ws, uint32_t every);
 
 /* ------------------------------------------------------------------------- */
 /* Host post-steps kept bit-compatible with the reference (they stay on the    */

@@ -108,6 +108,7 @@ SYMBOLS = {
     "kaamer_workspace_kernel_ms_sum": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                                  C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
     "kaamer_workspace_reset_timers": (None, [C.c_void_p]),
+    "kaamer_workspace_set_timing": (None, [C.c_void_p, C.c_uint32]),
     "kaamer_filter_results": (C.c_int64, [C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_int64, C.c_int64]),
     "kaamer_sort_hits": (None, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "kaamer_set_best_start_codon": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32,

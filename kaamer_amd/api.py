@@ -245,6 +245,10 @@ class Workspace:
     def reset_timers(self):
         abi.lib().kaamer_workspace_reset_timers(self._h)
 
+    def set_timing(self, every):
+        """0: no kernel timers (default); k: HIP events around the kernels of every k-th call"""
+        abi.lib().kaamer_workspace_set_timing(self._h, int(every))
+
     def close(self):
         if self._h:
             abi.lib().kaamer_workspace_free(self._h)

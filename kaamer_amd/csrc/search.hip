@@ -68,7 +68,7 @@ struct kaamer_index {
 };
 
 enum { ST_POOL_FULL = 1u, ST_LIST_FULL = 2u, ST_QUERY_CAP = 4u, ST_AA_CAP = 8u, ST_G_ARENA_FULL = 16u, ST_G_TABLE_FULL = 32u,
-       ST_POS_UNSUPPORTED = 64u, ST_POS_CAP = 128u };
+       ST_POS_UNSUPPORTED = 64u, ST_POS_CAP = 128u, ST_CHAIN_TIMEOUT = 256u };
 enum { CTR_IN = 0, CTR_QUERIES, CTR_LOOKUP, CTR_PROBE, CTR_FOUND, CTR_POST, CTR_HITS, CTR_OVERFLOW, CTR_LISTS, CTR_LIST_IDS, CTR_N };
 static_assert(sizeof(kaamer_counters) == CTR_N * 8, "counter layout");
 #define CTR_REPLICAS 64
@@ -277,7 +277,7 @@ struct CountParams {
     WorkItem *ovf_list;
     uint32_t *ovf_count;
     uint32_t list_cap;
-    uint32_t *queue_head;  // dynamic dequeue for the S tier
+    uint32_t *queue_head;  // workgroups of the last kernel that have finished (zeroed by finalize)
     // results, written straight into their final place: hits of query q are
     // [hit_off[q], hit_off[q] + q_cnt[q]) of the three SoA arrays.  The arrays are split into
     // HIT_SHARDS regions, each filled from its own cursor (exact reservations, one per query
@@ -297,6 +297,10 @@ struct CountParams {
     uint32_t n_proteins;
     unsigned long long *counters;  // [CTR_REPLICAS][CTR_N]
     uint32_t *status;
+    // set when count_global_kernel is the last kernel of the batch: its last workgroup finalizes
+    kaamer_counters *fin_out;
+    uint32_t *fin_small, *fin_status_out;
+    unsigned long long *fin_cursors;
 };
 
 // exact reservation of `total` hit entries on this workgroup's shard cursor
@@ -517,6 +521,34 @@ struct NullTable {
     __device__ __forceinline__ bool over_limit() const { return false; }
 };
 
+// Sums the counter replicas, publishes status, and leaves every piece of per-batch device
+// state zeroed for the next batch (no memsets in the steady state).  One workgroup.
+// IN_FLIGHT: called by the last workgroup of a running kernel.  Everything read here was written
+// with device-scope atomics (performed at the memory side), so device-scope atomic loads see
+// it without an agent-scope fence -- which on this part writes back the whole L2 (a fence per
+// workgroup made the kernel 30x slower).
+template <bool IN_FLIGHT>
+__device__ __forceinline__ void finalize_body(unsigned long long *replicas, kaamer_counters *out, uint32_t *small_state,
+                                              uint32_t *status_out, unsigned long long *cursors)
+{
+    // 256 threads: lane <-> replica, wave w sums counters w, w+4, ...
+    static_assert(CTR_REPLICAS == 64, "one replica per lane");
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    for (uint32_t c = wv; c < CTR_N; c += blockDim.x >> 6) {
+        unsigned long long *w = &replicas[(size_t)lane * CTR_N + c];
+        unsigned long long s = IN_FLIGHT ? __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *w;
+        *w = 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) ((unsigned long long *)out)[c] = s;
+    }
+    if (threadIdx.x == 0)
+        *status_out = IN_FLIGHT ? __hip_atomic_load(&small_state[N_LISTS + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : small_state[N_LISTS + 1];
+    __syncthreads();
+    if (threadIdx.x < N_LISTS + 2) small_state[threadIdx.x] = 0;
+    for (uint32_t i = threadIdx.x; i <= HIT_SHARDS; i += blockDim.x) cursors[i * CURSOR_STRIDE] = 0;  // + the G arena cursor
+}
+
 __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams p)
 {
     constexpr int WAVES = G_WAVES;
@@ -612,6 +644,17 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
     if (lane == 0) {
         const uint32_t rep = blockIdx.x * WAVES + wv;
         add_counter(p.counters, rep, CTR_HITS, tot_hits);
+    }
+    if (p.fin_out) {
+        // the batch ends here: the last workgroup to arrive does the finalize step
+        __shared__ uint32_t s_last;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this wave's counter atomics are done
+        __syncthreads();
+        if (tid == 0) s_last = atomicAdd(p.queue_head, 1u) == gridDim.x - 1u;
+        __syncthreads();
+        if (s_last) {
+            finalize_body<true>(p.counters, p.fin_out, p.fin_small, p.fin_status_out, p.fin_cursors);
+        }
     }
 }
 
@@ -814,23 +857,10 @@ __global__ __launch_bounds__(256) void gather_hits_kernel(const uint32_t *d_nq, 
     }
 }
 
-// Sums the counter replicas, publishes status, and leaves every piece of per-batch device
-// state zeroed for the next batch (no memsets in the steady state).
 __global__ void finalize_kernel(unsigned long long *replicas, kaamer_counters *out, uint32_t *small_state,
                                 uint32_t *status_out, unsigned long long *cursors)
 {
-    if (threadIdx.x < CTR_N) {
-        unsigned long long s = 0;
-        for (int r = 0; r < CTR_REPLICAS; r++) {
-            s += replicas[(size_t)r * CTR_N + threadIdx.x];
-            replicas[(size_t)r * CTR_N + threadIdx.x] = 0;
-        }
-        ((unsigned long long *)out)[threadIdx.x] = s;
-    }
-    if (threadIdx.x == 0) *status_out = small_state[N_LISTS + 1];
-    __syncthreads();
-    if (threadIdx.x < N_LISTS + 2) small_state[threadIdx.x] = 0;
-    for (uint32_t i = threadIdx.x; i <= HIT_SHARDS; i += blockDim.x) cursors[i * CURSOR_STRIDE] = 0;  // + the G arena cursor
+    finalize_body<false>(replicas, out, small_state, status_out, cursors);
 }
 
 // ------------------------------------------------------------------------------------
@@ -871,8 +901,8 @@ struct kaamer_workspace {
     uint8_t *d_orf_aa;
     int32_t *d_starts_alt;
     uint32_t max_seqs;
-    hipStream_t side;                   // the L tier runs beside the S tier
-    hipEvent_t ev_fork, ev_join;
+    unsigned long long *d_chain;        // layout_kernel: one word per tile, tagged with the batch epoch
+    uint32_t lay_epoch;
     uint32_t *d_list_counts;            // [N_LISTS] + queue head + status (zeroed by finalize)
     uint32_t *d_status_out;             // status of the last finished batch
     bool clean;                         // per-batch device state is known to be zeroed
@@ -886,13 +916,12 @@ struct kaamer_workspace {
     uint32_t *d_g_keys, *d_g_cnt, *d_g_min;
     unsigned long long *d_counter_replicas;
     kaamer_counters *d_counters;
-    uint64_t *d_bsum, *d_bsum2;
+    uint64_t *d_bsum;
     uint32_t n_scan_blocks;
     uint64_t *d_hit_off;
     uint32_t *d_hit_pid, *d_hit_km, *d_hit_fp;
     std::vector<hipEvent_t> *ev;  // 5 events per timed call: total0, probe0, probe1(=count0), count1, total1
-    uint32_t n_timed;
-    bool timed;
+    uint32_t n_timed, time_every, call_no;
 };
 enum { SLOT_QUEUE_HEAD = N_LISTS, SLOT_STATUS = N_LISTS + 1, N_SMALL_SLOTS = N_LISTS + 2 };
 #define EV_PER_CALL 5
@@ -979,16 +1008,13 @@ void kaamer_workspace_free(kaamer_workspace *ws)
                      ws->d_tmp_meta, ws->d_orf_aa, ws->d_starts_alt, ws->d_q_cnt, ws->d_csr_off, ws->d_c_pid, ws->d_c_km, ws->d_c_fp,
                      ws->d_pool_cursor, ws->d_lists, ws->d_list_counts, ws->d_status_out, ws->d_qinfo, ws->d_slots,
                      ws->d_slot_off, ws->d_group_first, ws->d_n_groups, ws->d_pos_words, ws->d_pos_base, ws->d_pos_off, ws->d_pos_bits, ws->d_g_keys,
-                     ws->d_g_cnt, ws->d_g_min, ws->d_counter_replicas, ws->d_counters, ws->d_bsum, ws->d_bsum2, ws->d_hit_off,
+                     ws->d_g_cnt, ws->d_g_min, ws->d_counter_replicas, ws->d_counters, ws->d_bsum, ws->d_chain, ws->d_hit_off,
                      ws->d_hit_pid, ws->d_hit_km, ws->d_hit_fp };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (ws->ev) {
         for (hipEvent_t e : *ws->ev) (void)hipEventDestroy(e);
         delete ws->ev;
     }
-    if (ws->ev_fork) (void)hipEventDestroy(ws->ev_fork);
-    if (ws->ev_join) (void)hipEventDestroy(ws->ev_join);
-    if (ws->side) (void)hipStreamDestroy(ws->side);
     delete ws;
 }
 
@@ -1034,7 +1060,7 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     if (p_per_cu < 1) p_per_cu = 1;
     ws->n_cu = prop.multiProcessorCount;
     ws->grp_grid = ws->n_cu * grp_per_cu;
-    ws->g_grid = ws->n_cu * 2;
+    ws->g_grid = ws->n_cu / 2;  // the G tier is rare; its last workgroup also finalizes the batch (one atomic per workgroup)
     ws->p_grid = ws->n_cu * p_per_cu;
     // a table has at most max(64, 3 x SizeInKmer) slots
     {
@@ -1086,7 +1112,8 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     if (!rc) rc = dev_alloc(&ws->d_counter_replicas, (size_t)CTR_REPLICAS * CTR_N);
     if (!rc) rc = dev_alloc(&ws->d_counters, 1);
     if (!rc) rc = dev_alloc(&ws->d_bsum, ws->n_scan_blocks);
-    if (!rc) rc = dev_alloc(&ws->d_bsum2, ws->n_scan_blocks);
+    if (!rc) rc = dev_alloc(&ws->d_chain, (size_t)ws->q_cap / LAY_TILE + 2);
+    if (!rc && hipMemset(ws->d_chain, 0, ((size_t)ws->q_cap / LAY_TILE + 2) * sizeof(unsigned long long)) != hipSuccess) rc = kaamer_fail(KAAMER_E_HIP, "memset");
     if (!rc) rc = dev_alloc(&ws->d_hit_off, (size_t)ws->q_cap + 1);
     // the 64 shard regions fill unevenly (+50 %)
     ws->sparse_cap = ((ws->hit_cap + ws->hit_cap / 2 + HIT_SHARDS * 8192ull) + HIT_SHARDS - 1) / HIT_SHARDS * HIT_SHARDS;
@@ -1105,14 +1132,18 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     if (rc) { kaamer_workspace_free(ws); return rc; }
     ws->ev = new (std::nothrow) std::vector<hipEvent_t>();
     if (!ws->ev) { kaamer_workspace_free(ws); return kaamer_fail(KAAMER_E_NOMEM, "event ring"); }
-    {
-        hipError_t e = hipStreamCreateWithFlags(&ws->side, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ws->ev_fork, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ws->ev_join, hipEventDisableTiming);
-        if (e != hipSuccess) { kaamer_workspace_free(ws); return kaamer_fail(KAAMER_E_HIP, "side stream: %s", hipGetErrorString(e)); }
-    }
     *out = ws;
     return KAAMER_OK;
+}
+
+// table layout + query groups (count_group.hip.inc): one single-pass kernel
+static void launch_layout(kaamer_workspace *ws, uint32_t nq_bound, uint32_t *status, hipStream_t s)
+{
+    ws->lay_epoch = (ws->lay_epoch + 1u) & 0xFFFFFFu;
+    if (ws->lay_epoch == 0) ws->lay_epoch = 1;
+    const uint32_t tiles = (uint32_t)(((uint64_t)nq_bound + 1 + LAY_TILE - 1) / LAY_TILE);
+    hipLaunchKernelGGL(layout_kernel, dim3(tiles), dim3(LAY_THREADS), 0, s, ws->d_slots, ws->d_nq, ws->d_slot_off, ws->d_group_first,
+                       ws->d_n_groups, ws->groups_cap, ws->d_chain, ws->lay_epoch, status);
 }
 
 // optional last step of a search / merge: CSR in query order from the sharded hit arrays
@@ -1156,21 +1187,26 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     if (seq_bytes > ws->opts.max_seq_bytes) return kaamer_fail(KAAMER_E_CAPACITY, "batch of %llu bytes exceeds workspace max_seq_bytes", (unsigned long long)seq_bytes);
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(ix->device));
-    if (ws->n_timed >= MAX_TIMED_CALLS) ws->n_timed = 0;
-    while (ws->ev->size() < (size_t)(ws->n_timed + 1) * EV_PER_CALL) {
-        hipEvent_t e;
-        HIPCHK(hipEventCreate(&e));
-        ws->ev->push_back(e);
+    // kernel timers: an event record costs a few microseconds of stream idle time, so they are
+    // off unless asked for, and can sample every k-th call (kaamer_workspace_set_timing)
+    const bool timed = ws->time_every && (ws->call_no++ % ws->time_every) == 0;
+    hipEvent_t *ev = nullptr;
+    if (timed) {
+        if (ws->n_timed >= MAX_TIMED_CALLS) ws->n_timed = 0;
+        while (ws->ev->size() < (size_t)(ws->n_timed + 1) * EV_PER_CALL) {
+            hipEvent_t e;
+            HIPCHK(hipEventCreate(&e));
+            ws->ev->push_back(e);
+        }
+        ev = ws->ev->data() + (size_t)ws->n_timed * EV_PER_CALL;
+        HIPCHK(hipEventRecord(ev[0], s));
     }
-    hipEvent_t *ev = ws->ev->data() + (size_t)ws->n_timed * EV_PER_CALL;
-    HIPCHK(hipEventRecord(ev[0], s));
     if (!ws->clean) {
         // first batch, or a previous batch did not run to its finalize kernel
         HIPCHK(hipMemsetAsync(ws->d_pool_cursor, 0, (size_t)(HIT_SHARDS + 1) * CURSOR_STRIDE * sizeof(unsigned long long), s));
         HIPCHK(hipMemsetAsync(ws->d_list_counts, 0, N_SMALL_SLOTS * sizeof(uint32_t), s));
         HIPCHK(hipMemsetAsync(ws->d_counter_replicas, 0, sizeof(unsigned long long) * CTR_REPLICAS * CTR_N, s));
         HIPCHK(hipMemsetAsync(ws->d_valid, 0, (size_t)(ws->pos_cap / 64 + 2) * sizeof(unsigned long long), s));
-        HIPCHK(hipMemsetAsync(ws->d_group_first, 0xFF, (size_t)ws->groups_cap * sizeof(uint32_t), s));
     }
     ws->clean = false;
 
@@ -1180,7 +1216,6 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     const uint8_t *residues = d_seqs;   // what kernel P reads: the protein records, or the ORF amino acids
     uint64_t pos_bound = seq_bytes;     // host-side bound of the residue positions (grid sizing only)
     uint32_t nq_bound = n_seqs;         // host-side bound of the number of queries
-    const bool small_prep = false;
     if (!nucl) {
         hipLaunchKernelGGL(prep_protein_kernel, dim3((n_seqs + pb - 1) / pb > 0 ? (n_seqs + pb - 1) / pb : 1), dim3(pb), 0, s,
                            d_seqs, d_offsets, n_seqs, ws->d_q, ws->d_nq, ws->d_n_pos, ws->d_valid, ws->d_qinfo, ws->d_slots,
@@ -1221,28 +1256,8 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         nq_bound = ws->q_cap;
     }
 
-    // ---- query groups: scan of the table capacities + first query of each group, on the side
-    // stream beside kernels P and H (they only share prep's outputs)
-    if (!small_prep) {
-    HIPCHK(hipEventRecord(ws->ev_fork, s));
-    HIPCHK(hipStreamWaitEvent(ws->side, ws->ev_fork, 0));
-    if (nq_bound <= 8 * SCAN_TILE) {
-        hipLaunchKernelGGL(scan_single_kernel, dim3(1), dim3(SCAN_BLOCK), 0, ws->side, ws->d_slots, ws->d_nq, ws->d_slot_off);
-    } else {
-        const uint32_t nsb = (uint32_t)(((uint64_t)nq_bound + 1 + SCAN_TILE - 1) / SCAN_TILE);
-        hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nsb), dim3(SCAN_BLOCK), 0, ws->side, ws->d_slots, ws->d_nq, ws->d_bsum2);
-        hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_BLOCK), 0, ws->side, ws->d_bsum2, nsb);
-        hipLaunchKernelGGL(scan_apply_kernel, dim3(nsb), dim3(SCAN_BLOCK), 0, ws->side, ws->d_slots, ws->d_nq, ws->d_bsum2, ws->d_slot_off);
-    }
-    {
-        uint32_t gb = (nq_bound + 255) / 256;
-        if (gb < 1) gb = 1;
-        if (gb > (uint32_t)ws->n_cu * 8) gb = (uint32_t)ws->n_cu * 8;
-        hipLaunchKernelGGL(group_build_kernel, dim3(gb), dim3(256), 0, ws->side, ws->d_qinfo, ws->d_slot_off, ws->d_nq,
-                           ws->d_group_first, ws->d_n_groups, ws->groups_cap, status);
-    }
-    HIPCHK(hipEventRecord(ws->ev_join, ws->side));
-    }
+    // ---- query groups: table layout and the first query of each group
+    launch_layout(ws, nq_bound, status, s);
 
     // ---- kernel P: flat probe
     ProbeParams pp;
@@ -1258,9 +1273,9 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     uint64_t p_blocks = (pos_bound / 64 + 1 + P_WAVES - 1) / P_WAVES;
     if (p_blocks > (uint64_t)ws->p_grid) p_blocks = ws->p_grid;
     if (p_blocks < 1) p_blocks = 1;
-    HIPCHK(hipEventRecord(ev[1], s));
+    if (timed) HIPCHK(hipEventRecord(ev[1], s));
     hipLaunchKernelGGL(probe_kernel, dim3((unsigned)p_blocks), dim3(64 * P_WAVES), 0, s, pp);
-    HIPCHK(hipEventRecord(ev[2], s));
+    if (timed) HIPCHK(hipEventRecord(ev[2], s));
     // ---- kernel C: counting
     CountParams p;
     memset(&p, 0, sizeof p);
@@ -1290,7 +1305,6 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     p.status = status;
     auto list_ptr = [&](int which) { return ws->d_lists + (size_t)which * ws->q_cap; };
 
-    if (!small_prep) HIPCHK(hipStreamWaitEvent(s, ws->ev_join, 0));
     CountParams pc = p;
     pc.ovf_list = list_ptr(LIST_G); pc.ovf_count = ws->d_list_counts + LIST_G;
     pc.last_group_pass = ws->want_positions ? 0u : 1u;
@@ -1306,9 +1320,14 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     pg.list = list_ptr(LIST_G); pg.list_count = ws->d_list_counts + LIST_G;
     int g_grid = ws->g_grid;
     if ((uint32_t)g_grid > nq_bound) g_grid = nq_bound > 0 ? (int)nq_bound : 1;
+    const bool fused_finalize = !ws->compact && !ws->want_positions;
+    if (fused_finalize) {
+        pg.fin_out = ws->d_counters; pg.fin_small = ws->d_list_counts; pg.fin_status_out = ws->d_status_out;
+        pg.fin_cursors = ws->d_pool_cursor;
+    }
     hipLaunchKernelGGL(count_global_kernel, dim3(g_grid), dim3(64 * G_WAVES), 0, s, pg);
     if (ws->compact) launch_compaction(ws, nq_bound, status, s);
-    HIPCHK(hipEventRecord(ev[3], s));
+    if (timed) HIPCHK(hipEventRecord(ev[3], s));
 
     if (ws->want_positions) {
         // PositionHits bitmaps (search.go:442-452): layout from the final hit lists, then one more
@@ -1335,13 +1354,13 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         pp2.ovf_list = list_ptr(LIST_SO); pp2.ovf_count = ws->d_list_counts + LIST_SO;
         launch_group_positions(pp2, (int)grp_blocks, s);
     }
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, s, ws->d_counter_replicas, ws->d_counters, ws->d_list_counts,
-                       ws->d_status_out, ws->d_pool_cursor);
-    HIPCHK(hipEventRecord(ev[4], s));
+    if (!fused_finalize)
+        hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->d_counter_replicas, ws->d_counters, ws->d_list_counts,
+                           ws->d_status_out, ws->d_pool_cursor);
+    if (timed) HIPCHK(hipEventRecord(ev[4], s));
     HIPCHK(hipGetLastError());
     ws->clean = true;  // everything up to finalize is enqueued
-    ws->n_timed++;
-    ws->timed = true;
+    if (timed) ws->n_timed++;
 
     out->n_queries_cap = ws->q_cap;
     out->d_n_queries = ws->d_nq;
@@ -1370,7 +1389,6 @@ int kaamer_merge_device(kaamer_workspace *ws, const uint64_t *d_ent_off, const u
         HIPCHK(hipMemsetAsync(ws->d_list_counts, 0, N_SMALL_SLOTS * sizeof(uint32_t), s));
         HIPCHK(hipMemsetAsync(ws->d_counter_replicas, 0, sizeof(unsigned long long) * CTR_REPLICAS * CTR_N, s));
         HIPCHK(hipMemsetAsync(ws->d_valid, 0, (size_t)(ws->pos_cap / 64 + 2) * sizeof(unsigned long long), s));
-        HIPCHK(hipMemsetAsync(ws->d_group_first, 0xFF, (size_t)ws->groups_cap * sizeof(uint32_t), s));
     }
     ws->clean = false;
     uint32_t *status = ws->d_list_counts + SLOT_STATUS;
@@ -1378,21 +1396,7 @@ int kaamer_merge_device(kaamer_workspace *ws, const uint64_t *d_ent_off, const u
     const int pb = 256;
     hipLaunchKernelGGL(prep_merge_kernel, dim3((n_queries + pb - 1) / pb > 0 ? (n_queries + pb - 1) / pb : 1), dim3(pb), 0, s, d_ent_off,
                        n_queries, ws->d_qinfo, ws->d_slots, ws->d_nq, ws->d_hit_off, ws->d_q_cnt);
-    if (nq_bound <= 8 * SCAN_TILE) {
-        hipLaunchKernelGGL(scan_single_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, ws->d_slots, ws->d_nq, ws->d_slot_off);
-    } else {
-        const uint32_t nsb = (uint32_t)(((uint64_t)nq_bound + 1 + SCAN_TILE - 1) / SCAN_TILE);
-        hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nsb), dim3(SCAN_BLOCK), 0, s, ws->d_slots, ws->d_nq, ws->d_bsum2);
-        hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, ws->d_bsum2, nsb);
-        hipLaunchKernelGGL(scan_apply_kernel, dim3(nsb), dim3(SCAN_BLOCK), 0, s, ws->d_slots, ws->d_nq, ws->d_bsum2, ws->d_slot_off);
-    }
-    {
-        uint32_t gb = (nq_bound + 255) / 256;
-        if (gb < 1) gb = 1;
-        if (gb > (uint32_t)ws->n_cu * 8) gb = (uint32_t)ws->n_cu * 8;
-        hipLaunchKernelGGL(group_build_kernel, dim3(gb), dim3(256), 0, s, ws->d_qinfo, ws->d_slot_off, ws->d_nq, ws->d_group_first,
-                           ws->d_n_groups, ws->groups_cap, status);
-    }
+    launch_layout(ws, nq_bound, status, s);
     CountParams p;
     memset(&p, 0, sizeof p);
     p.qinfo = ws->d_qinfo;
@@ -1426,7 +1430,7 @@ int kaamer_merge_device(kaamer_workspace *ws, const uint64_t *d_ent_off, const u
     if ((uint32_t)g_grid > nq_bound) g_grid = nq_bound > 0 ? (int)nq_bound : 1;
     hipLaunchKernelGGL(merge_global_kernel, dim3(g_grid), dim3(256), 0, s, pg);
     if (ws->compact) launch_compaction(ws, nq_bound, status, s);
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(64), 0, s, ws->d_counter_replicas, ws->d_counters, ws->d_list_counts,
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->d_counter_replicas, ws->d_counters, ws->d_list_counts,
                        ws->d_status_out, ws->d_pool_cursor);
     HIPCHK(hipGetLastError());
     ws->clean = true;
@@ -1451,6 +1455,7 @@ int kaamer_workspace_finish(kaamer_workspace *ws, void *stream, kaamer_counters 
     if (status) ws->clean = false;  // an aborted batch may leave per-batch state behind
     if (status & ST_POOL_FULL) return kaamer_fail(KAAMER_E_CAPACITY, "hit pool exhausted: raise workspace max_hits (now %llu)", (unsigned long long)ws->hit_cap);
     if (status & ST_LIST_FULL) return kaamer_fail(KAAMER_E_CAPACITY, "tier work list exhausted");
+    if (status & ST_CHAIN_TIMEOUT) return kaamer_fail(KAAMER_E_HIP, "table layout: a tile never published its total");
     if (status & (ST_QUERY_CAP | ST_AA_CAP))
         return kaamer_fail(KAAMER_E_CAPACITY, "more ORFs than the workspace holds: raise workspace max_queries (now %u)", ws->q_cap);
     if (status & ST_POS_CAP) return kaamer_fail(KAAMER_E_CAPACITY, "position bitmaps exceed the workspace: raise max_pos_words (now %llu)", (unsigned long long)ws->bits_cap);
@@ -1487,7 +1492,12 @@ int kaamer_workspace_kernel_ms_sum(kaamer_workspace *ws, double *probe_ms, doubl
 
 void kaamer_workspace_reset_timers(kaamer_workspace *ws)
 {
-    if (ws) ws->n_timed = 0;
+    if (ws) { ws->n_timed = 0; ws->call_no = 0; }
+}
+
+void kaamer_workspace_set_timing(kaamer_workspace *ws, uint32_t every)
+{
+    if (ws) { ws->time_every = every; ws->call_no = 0; }
 }
 
 // ------------------------------------------------------------------------------------

@@ -207,6 +207,7 @@ def test_device_resident_call_and_reuse(small, oracle):
     stream = torch.cuda.Stream()
     for seed in (1, 2, 3):
         ws = api.Workspace(ix, 1 << 20, 500, compact=(seed == 2))
+        ws.set_timing(1)
         q = workload.make_protein_queries(db, 300, seed=seed)
         buf, offs = q
         with torch.cuda.stream(stream):
