@@ -75,6 +75,9 @@ static_assert(sizeof(kaamer_counters) == CTR_N * 8, "counter layout");
 
 // work lists of the counting tiers (device memory)
 enum { LIST_S = 0, LIST_L, LIST_SO, LIST_G, N_LISTS };
+// small per-batch device state after the list counters (all zeroed by the finalize step)
+enum { SLOT_QUEUE_HEAD = N_LISTS, SLOT_STATUS = N_LISTS + 1, SLOT_GROUP_QUEUE = N_LISTS + 2, SLOT_GROUP_QUEUE_POS = N_LISTS + 3,
+       N_SMALL_SLOTS = N_LISTS + 4 };
 // one entry: everything a tier needs to start on a query, in one 16-byte load
 struct alignas(16) WorkItem {
     uint32_t q;
@@ -82,7 +85,6 @@ struct alignas(16) WorkItem {
     uint64_t aa_off;  // first residue position of the query
 };
 
-#define HIT_SHARDS 64u
 #define CURSOR_STRIDE 32u  /* unsigned long long words between cursors (256 B) */
 #define MAX_TIMED_CALLS 1024u
 #define L_WAVES 8
@@ -278,18 +280,19 @@ struct CountParams {
     uint32_t *ovf_count;
     uint32_t list_cap;
     uint32_t *queue_head;  // workgroups of the last kernel that have finished (zeroed by finalize)
+    uint32_t *group_queue; // tickets of the group kernel (zeroed by finalize)
     // results, written straight into their final place: hits of query q are
-    // [hit_off[q], hit_off[q] + q_cnt[q]) of the three SoA arrays.  The arrays are split into
-    // HIT_SHARDS regions, each filled from its own cursor (exact reservations, one per query
-    // group); an optional pass compacts them into CSR in query order.
-    // (An ordered single-pass layout by decoupled look-back over the groups was measured: groups
-    // then wait for every slower lower-numbered group, +30 us per batch, as much as the
-    // compaction pass it saves.)
+    // [hit_off[q], hit_off[q] + q_cnt[q]) of the three SoA arrays, with hit_off[q] = E[q], the
+    // first slot of the query's counting table in the batch's table layout (a table never holds
+    // more distinct ids than its capacity): no allocation, no atomics.  G-tier queries (rare)
+    // take space after E[n_queries] from a cursor.  An optional pass packs the lists (CSR).
+    // (Measured and dropped: exact reservations on 64 cursors, +1 exposed atomic round trip and a
+    // counting pass per group; an ordered layout by look-back over the groups, +30 us.)
     uint64_t *hit_off;
     uint32_t *q_cnt;
     uint32_t *hit_pid, *hit_km, *hit_fp;
-    uint64_t hit_shard_cap;           // entries per shard region
-    unsigned long long *hit_cursor;   // [HIT_SHARDS] cursors, CURSOR_STRIDE apart, relative to the region
+    uint64_t hit_cap;                 // entries of the hit arrays
+    unsigned long long *tail_cursor;  // entries handed out after E[n_queries] (G tier)
     // G tier arena
     uint32_t *g_keys, *g_cnt, *g_min;
     uint64_t g_slots;
@@ -303,13 +306,12 @@ struct CountParams {
     unsigned long long *fin_cursors;
 };
 
-// exact reservation of `total` hit entries on this workgroup's shard cursor
-__device__ __forceinline__ unsigned long long shard_alloc(const CountParams &p, uint32_t total)
+// G-tier hit lists live after the table layout's total
+__device__ __forceinline__ unsigned long long tail_alloc(const CountParams &p, uint32_t total)
 {
-    const uint32_t shard = blockIdx.x % HIT_SHARDS;
-    const unsigned long long b = atomicAdd(&p.hit_cursor[shard * CURSOR_STRIDE], (unsigned long long)total);
-    if (b + total > p.hit_shard_cap) { atomicOr(p.status, (uint32_t)ST_POOL_FULL); return ~0ull; }
-    return (unsigned long long)shard * p.hit_shard_cap + b;
+    const unsigned long long b = p.slot_off[*p.d_nq] + atomicAdd(p.tail_cursor, (unsigned long long)total);
+    if (b + total > p.hit_cap) { atomicOr(p.status, (uint32_t)ST_POOL_FULL); return ~0ull; }
+    return b;
 }
 
 // counting tables: protein id -> (count, lowest matching position)
@@ -543,10 +545,10 @@ __device__ __forceinline__ void finalize_body(unsigned long long *replicas, kaam
         if (lane == 0) ((unsigned long long *)out)[c] = s;
     }
     if (threadIdx.x == 0)
-        *status_out = IN_FLIGHT ? __hip_atomic_load(&small_state[N_LISTS + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : small_state[N_LISTS + 1];
+        *status_out = IN_FLIGHT ? __hip_atomic_load(&small_state[SLOT_STATUS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : small_state[SLOT_STATUS];
     __syncthreads();
-    if (threadIdx.x < N_LISTS + 2) small_state[threadIdx.x] = 0;
-    for (uint32_t i = threadIdx.x; i <= HIT_SHARDS; i += blockDim.x) cursors[i * CURSOR_STRIDE] = 0;  // + the G arena cursor
+    if (threadIdx.x < N_SMALL_SLOTS) small_state[threadIdx.x] = 0;
+    if (threadIdx.x < 2) cursors[threadIdx.x * CURSOR_STRIDE] = 0;  // G-tier tail cursor, G arena cursor
 }
 
 __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams p)
@@ -617,7 +619,7 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
         if (tid == 0) {
             if (failed) { atomicOr(p.status, (uint32_t)ST_G_TABLE_FULL); s_base = ~0ull; }
             else if (total == 0) s_base = 0;
-            else s_base = shard_alloc(p, total);
+            else s_base = tail_alloc(p, total);
         }
         __syncthreads();
         const unsigned long long base = s_base;
@@ -882,7 +884,7 @@ struct kaamer_workspace {
     unsigned long long *d_valid;        // one bit per residue position
     uint32_t *d_vals;                   // probe result per residue position
     uint32_t *d_q_cnt;
-    unsigned long long *d_pool_cursor;  // HIT_SHARDS hit cursors + the G arena cursor, CURSOR_STRIDE apart
+    unsigned long long *d_pool_cursor;  // [0] G-tier tail cursor, [CURSOR_STRIDE] G arena cursor
     WorkItem *d_lists;                  // [N_LISTS][q_cap] (only the G tier's overflow list is used)
     QInfo *d_qinfo;
     uint32_t *d_slots;
@@ -923,7 +925,6 @@ struct kaamer_workspace {
     std::vector<hipEvent_t> *ev;  // 5 events per timed call: total0, probe0, probe1(=count0), count1, total1
     uint32_t n_timed, time_every, call_no;
 };
-enum { SLOT_QUEUE_HEAD = N_LISTS, SLOT_STATUS = N_LISTS + 1, N_SMALL_SLOTS = N_LISTS + 2 };
 #define EV_PER_CALL 5
 
 template <class T> static int dev_alloc(T **p, size_t n)
@@ -1045,6 +1046,12 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     if (ws->q_cap < 1) ws->q_cap = 1;
     ws->hit_cap = opts->max_hits ? opts->max_hits : (uint64_t)ws->q_cap * 256 + (1u << 20);
     ws->g_slots = opts->g_tier_slots ? opts->g_tier_slots : (32ull << 20);
+    {
+        // hit arrays: the lists sit at the table layout's offsets (<= 1.5 x positions + 64 per query;
+        // for a merge the "positions" are partial entries), G-tier lists after them
+        const uint64_t items = ws->pos_cap > ws->hit_cap ? ws->pos_cap : ws->hit_cap;
+        ws->sparse_cap = items + items / 2 + 64ull * ws->q_cap + GRP_MAX_TABLE + ws->hit_cap / 2 + (1u << 20);
+    }
     // the reference fills PositionHits only for nucleotide/reads input or with -pos (search.go:416)
     ws->firstpos = opts->first_pos == 1 || (opts->first_pos == 0 && (opts->seq_type == KAAMER_NUCLEOTIDE || opts->seq_type == KAAMER_READS));
     int grp_per_cu = 0, p_per_cu = 0;
@@ -1088,7 +1095,7 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
         if (!rc) rc = dev_alloc(&ws->d_starts_alt, (size_t)ws->sa_cap + 64);
     }
     if (!rc) rc = dev_alloc(&ws->d_q_cnt, ws->q_cap);
-    if (!rc) rc = dev_alloc(&ws->d_pool_cursor, (size_t)(HIT_SHARDS + 1) * CURSOR_STRIDE);
+    if (!rc) rc = dev_alloc(&ws->d_pool_cursor, (size_t)2 * CURSOR_STRIDE);
     if (!rc) rc = dev_alloc(&ws->d_lists, (size_t)N_LISTS * ws->q_cap);
     if (!rc) rc = dev_alloc(&ws->d_list_counts, N_SMALL_SLOTS);
     if (!rc) rc = dev_alloc(&ws->d_status_out, 1);
@@ -1103,7 +1110,7 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
         ws->bits_cap = opts->max_pos_words ? opts->max_pos_words : ws->hit_cap * 8;
         rc = dev_alloc(&ws->d_pos_words, ws->q_cap);
         if (!rc) rc = dev_alloc(&ws->d_pos_base, (size_t)ws->q_cap + 1);
-        if (!rc) rc = dev_alloc(&ws->d_pos_off, ws->hit_cap + ws->hit_cap / 2 + HIT_SHARDS * 8192ull + HIT_SHARDS);
+        if (!rc) rc = dev_alloc(&ws->d_pos_off, ws->sparse_cap);
         if (!rc) rc = dev_alloc(&ws->d_pos_bits, ws->bits_cap);
     }
     if (!rc) rc = dev_alloc(&ws->d_g_keys, ws->g_slots);
@@ -1115,8 +1122,6 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     if (!rc) rc = dev_alloc(&ws->d_chain, (size_t)ws->q_cap / LAY_TILE + 2);
     if (!rc && hipMemset(ws->d_chain, 0, ((size_t)ws->q_cap / LAY_TILE + 2) * sizeof(unsigned long long)) != hipSuccess) rc = kaamer_fail(KAAMER_E_HIP, "memset");
     if (!rc) rc = dev_alloc(&ws->d_hit_off, (size_t)ws->q_cap + 1);
-    // the 64 shard regions fill unevenly (+50 %)
-    ws->sparse_cap = ((ws->hit_cap + ws->hit_cap / 2 + HIT_SHARDS * 8192ull) + HIT_SHARDS - 1) / HIT_SHARDS * HIT_SHARDS;
     ws->compact = opts->compact != 0;
     if (!rc) rc = dev_alloc(&ws->d_hit_pid, ws->sparse_cap);
     if (!rc) rc = dev_alloc(&ws->d_hit_km, ws->sparse_cap);
@@ -1203,7 +1208,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     }
     if (!ws->clean) {
         // first batch, or a previous batch did not run to its finalize kernel
-        HIPCHK(hipMemsetAsync(ws->d_pool_cursor, 0, (size_t)(HIT_SHARDS + 1) * CURSOR_STRIDE * sizeof(unsigned long long), s));
+        HIPCHK(hipMemsetAsync(ws->d_pool_cursor, 0, (size_t)2 * CURSOR_STRIDE * sizeof(unsigned long long), s));
         HIPCHK(hipMemsetAsync(ws->d_list_counts, 0, N_SMALL_SLOTS * sizeof(uint32_t), s));
         HIPCHK(hipMemsetAsync(ws->d_counter_replicas, 0, sizeof(unsigned long long) * CTR_REPLICAS * CTR_N, s));
         HIPCHK(hipMemsetAsync(ws->d_valid, 0, (size_t)(ws->pos_cap / 64 + 2) * sizeof(unsigned long long), s));
@@ -1288,18 +1293,19 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     p.d_nq = ws->d_nq;
     p.list_cap = ws->q_cap;
     p.queue_head = queue_head;
+    p.group_queue = ws->d_list_counts + SLOT_GROUP_QUEUE;
     p.hit_off = ws->d_hit_off;
     p.q_cnt = ws->d_q_cnt;
     p.hit_pid = ws->d_hit_pid;
     p.hit_km = ws->d_hit_km;
     p.hit_fp = ws->d_hit_fp;
-    p.hit_shard_cap = ws->sparse_cap / HIT_SHARDS;
-    p.hit_cursor = ws->d_pool_cursor;
+    p.hit_cap = ws->sparse_cap;
+    p.tail_cursor = ws->d_pool_cursor;
     p.g_keys = ws->d_g_keys;
     p.g_cnt = ws->d_g_cnt;
     p.g_min = ws->d_g_min;
     p.g_slots = ws->g_slots;
-    p.g_cursor = ws->d_pool_cursor + (size_t)HIT_SHARDS * CURSOR_STRIDE;
+    p.g_cursor = ws->d_pool_cursor + CURSOR_STRIDE;
     p.n_proteins = ix->hdr.max_protein_id + 1u ? ix->hdr.max_protein_id + 1u : 0xFFFFFFFFu;
     p.counters = ws->d_counter_replicas;
     p.status = status;
@@ -1351,6 +1357,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         pp2.last_group_pass = 1u;
         pp2.pos_base = ws->d_pos_base;
         pp2.pos_bits = ws->d_pos_bits;
+        pp2.group_queue = ws->d_list_counts + SLOT_GROUP_QUEUE_POS;
         pp2.ovf_list = list_ptr(LIST_SO); pp2.ovf_count = ws->d_list_counts + LIST_SO;
         launch_group_positions(pp2, (int)grp_blocks, s);
     }
@@ -1385,7 +1392,7 @@ int kaamer_merge_device(kaamer_workspace *ws, const uint64_t *d_ent_off, const u
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(ws->device));
     if (!ws->clean) {
-        HIPCHK(hipMemsetAsync(ws->d_pool_cursor, 0, (size_t)(HIT_SHARDS + 1) * CURSOR_STRIDE * sizeof(unsigned long long), s));
+        HIPCHK(hipMemsetAsync(ws->d_pool_cursor, 0, (size_t)2 * CURSOR_STRIDE * sizeof(unsigned long long), s));
         HIPCHK(hipMemsetAsync(ws->d_list_counts, 0, N_SMALL_SLOTS * sizeof(uint32_t), s));
         HIPCHK(hipMemsetAsync(ws->d_counter_replicas, 0, sizeof(unsigned long long) * CTR_REPLICAS * CTR_N, s));
         HIPCHK(hipMemsetAsync(ws->d_valid, 0, (size_t)(ws->pos_cap / 64 + 2) * sizeof(unsigned long long), s));
@@ -1405,16 +1412,17 @@ int kaamer_merge_device(kaamer_workspace *ws, const uint64_t *d_ent_off, const u
     p.d_n_groups = ws->d_n_groups;
     p.d_nq = ws->d_nq;
     p.last_group_pass = 1u;
+    p.group_queue = ws->d_list_counts + SLOT_GROUP_QUEUE;
     p.m_pid = d_pid; p.m_km = d_km; p.m_fp = d_fp;
     p.list_cap = ws->q_cap;
     p.hit_off = ws->d_hit_off;
     p.q_cnt = ws->d_q_cnt;
     p.hit_pid = ws->d_hit_pid; p.hit_km = ws->d_hit_km; p.hit_fp = ws->d_hit_fp;
-    p.hit_shard_cap = ws->sparse_cap / HIT_SHARDS;
-    p.hit_cursor = ws->d_pool_cursor;
+    p.hit_cap = ws->sparse_cap;
+    p.tail_cursor = ws->d_pool_cursor;
     p.g_keys = ws->d_g_keys; p.g_cnt = ws->d_g_cnt; p.g_min = ws->d_g_min;
     p.g_slots = ws->g_slots;
-    p.g_cursor = ws->d_pool_cursor + (size_t)HIT_SHARDS * CURSOR_STRIDE;
+    p.g_cursor = ws->d_pool_cursor + CURSOR_STRIDE;
     p.counters = ws->d_counter_replicas;
     p.status = status;
     auto list_ptr = [&](int which) { return ws->d_lists + (size_t)which * ws->q_cap; };
