@@ -100,6 +100,9 @@ def main():
                          "lists are exchanged with one RCCL all-to-all and merged by the query's owner")
     ap.add_argument("--time-every", type=int, default=8,
                     help="bracket the kernels of every k-th timed step with HIP events (roofline.achieved is their average)")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="batches in flight: step i runs on workspace/stream i %% inflight, so the probe kernel of one batch "
+                         "(memory-request bound) overlaps the counting kernel of the previous one (LDS/latency bound)")
     ap.add_argument("--compact", type=int, default=0,
                     help="1: finish every batch with the hit lists packed in query order (one more scan + copy pass); "
                          "0 (default): each query's list stays where the counting kernel wrote it (offset + count per query)")
@@ -163,12 +166,24 @@ def main():
         def step():
             return searcher.step(d_buf, d_off, args.queries, len(qbuf), stream)
     else:
+        wss = [ws] + [api.Workspace(ix, len(qbuf), args.queries, seq_type=abi.READS if reads else abi.PROTEIN,
+                                    max_hits=(64 << 20) if reads else 0, compact=bool(args.compact))
+                      for _ in range(args.inflight - 1)]
+        extra_streams = [torch.cuda.Stream() for _ in range(args.inflight - 1)]  # kept alive
+        streams = [stream] + [x.cuda_stream for x in extra_streams]
+        step_no = [0]
+
         def step():
-            return ws.search_device(d_buf.data_ptr(), d_off.data_ptr(), args.queries, len(qbuf), stream=stream)
+            i = step_no[0] % args.inflight
+            step_no[0] += 1
+            return wss[i].search_device(d_buf.data_ptr(), d_off.data_ptr(), args.queries, len(qbuf), stream=streams[i])
 
     for _ in range(args.warmup):
         step()
     counters = (mws if sharded_mode else ws).finish(stream)  # also validates the batch (capacity / overflow)
+    if not sharded_mode:
+        for w_, s_ in zip(wss[1:], streams[1:]):
+            w_.finish(s_)
     ws.set_timing(args.time_every)  # sampled: an event record idles the stream for a few microseconds
     ws.reset_timers()
 
@@ -188,6 +203,8 @@ def main():
         counters = step()[2]  # the local search's counters (one extra, untimed step)
         mws.finish(stream)
     else:
+        for w_, s_ in zip(wss[1:], streams[1:]):
+            w_.finish(s_)
         counters = ws.finish(stream)
     tm = ws.kernel_ms_sum()
     n_calls = max(tm["calls"], 1)
@@ -229,7 +246,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                 "random_request_ceiling": {"G_requests_per_s": 51.0, "achieved_G_probes_per_s": c["n_probe"] / probe_s / 1e9 if probe_s > 0 else 0.0,
                                            "source": "tools/random_read_bench.hip (profiles/r01_pmc_traffic_probe_kernel.json)"},
-                "kernel": "probe_kernel", "kernel_ms": probe_s * 1e3,
+                "kernel": "probe_kernel", "kernel_ms": probe_s * 1e3, "timed_launches": n_calls,
                 "algorithmic_bytes_per_launch": probe_bytes,
                 "bytes_per_lookup": probe_bytes / max(c["n_lookup"], 1),
                 "min_bytes_8B_slot": n_pos + n_pos // 8 + 8 * c["n_lookup"] + 4 * n_pos,
@@ -251,6 +268,7 @@ def main():
                                   else ("replicas x%d (no collective)" % world if world > 1 else "single GPU"),
                    "result": "device-resident per-query hit lists (offset, count, protein ids, Kmatch)" +
                              (", packed in query order" if args.compact else ""),
+                   "batches_in_flight": args.inflight,
                    "seed": workload.SEED},
         "query_seqs_per_s": queries_per_step * args.steps / elapsed,
         "counters_per_step_rank0": c,
