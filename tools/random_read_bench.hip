@@ -34,6 +34,50 @@ __global__ __launch_bounds__(256) void rr_kernel(const uint4 *table, uint64_t n_
     if (acc == 0x12345678u) sink[0] = acc;
 }
 
+// 64-B records read in PAIRS whose addresses differ by `stride` bytes (same aligned 2*stride block):
+// if two requests close in address and time cost less than two independent ones, the ceiling is
+// DRAM row activation (and the stride where the gain stops is the channel interleave), not the
+// request path.
+__global__ __launch_bounds__(256) void rr_pair_kernel(const uint4 *table, uint64_t n_records, uint32_t iters, uint32_t stride_recs,
+                                                      uint32_t *sink)
+{
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t grp = tid / 4, sub = tid % 4;
+    uint32_t acc = 0;
+    for (uint32_t it = 0; it < iters; it++) {
+        uint4 v[4];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const uint32_t h = mix32(grp * 0x9E3779B1u + (it * 2 + j) * 0x85ebca6bu + 12345u);
+            const uint64_t rec = (((uint64_t)h * n_records) >> 32) & ~(uint64_t)(2 * stride_recs - 1);
+            v[2 * j] = table[rec * 4 + sub];
+            v[2 * j + 1] = table[(rec + stride_recs) * 4 + sub];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc += v[j].x ^ v[j].y ^ v[j].z ^ v[j].w;
+    }
+    if (acc == 0x12345678u) sink[0] = acc;
+}
+
+static void run_pair(const uint4 *d, uint64_t bytes, uint32_t stride_bytes, uint32_t *sink)
+{
+    const uint64_t n_records = bytes / 64ull;
+    const int blocks = 256 * 8, threads = 256;
+    const uint32_t iters = 64;
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    hipLaunchKernelGGL(rr_pair_kernel, dim3(blocks), dim3(threads), 0, 0, d, n_records, 4u, stride_bytes / 64, sink);
+    hipDeviceSynchronize();
+    hipEventRecord(a);
+    hipLaunchKernelGGL(rr_pair_kernel, dim3(blocks), dim3(threads), 0, 0, d, n_records, iters, stride_bytes / 64, sink);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    const double recs = (double)blocks * threads / 4 * iters * 4;
+    printf("64-B records in pairs %6u B apart, table %5.0f MiB: %.2f G records/s\n", stride_bytes, bytes / 1048576.0, recs / ms / 1e6);
+}
+
 template <int G> static void run(const uint4 *d, uint64_t bytes, uint32_t *sink)
 {
     const uint64_t n_records = bytes / (16ull * G);
@@ -65,6 +109,9 @@ int main()
     run<2>(d, bytes, sink);
     run<4>(d, bytes, sink);
     run<8>(d, bytes, sink);
+    // footprint: does the request rate depend on the table size (Infinity Cache 256 MiB, TLB reach)?
+    for (uint64_t mb : {32ull, 128ull, 512ull, 1024ull}) { printf("table %4llu MiB: ", (unsigned long long)mb); run<4>(d, mb << 20, sink); }
+    for (uint32_t st : {64u, 128u, 256u, 512u, 1024u, 2048u, 4096u, 65536u}) run_pair(d, bytes, st, sink);
     // streaming reference: copy
     {
         hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
