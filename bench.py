@@ -100,6 +100,11 @@ def main():
                          "lists are exchanged with one RCCL all-to-all and merged by the query's owner")
     ap.add_argument("--time-every", type=int, default=8,
                     help="bracket the kernels of every k-th timed step with HIP events (roofline.achieved is their average)")
+    ap.add_argument("--post", type=int, default=0,
+                    help="1: every step also runs the device post-steps (sortMapByValue, SetBestStartCodon for reads, "
+                         "FilterResults: kaamer_topn_device with the reference's defaults)")
+    ap.add_argument("--host-api", type=int, default=0,
+                    help="1: also time the host-buffer calls once (PCIe-inclusive, informational, never `value`)")
     ap.add_argument("--inflight", type=int, default=1,
                     help="batches in flight: step i runs on workspace/stream i %% inflight, so the probe kernel of one batch "
                          "(memory-request bound) overlaps the counting kernel of the previous one (LDS/latency bound)")
@@ -176,7 +181,10 @@ def main():
         def step():
             i = step_no[0] % args.inflight
             step_no[0] += 1
-            return wss[i].search_device(d_buf.data_ptr(), d_off.data_ptr(), args.queries, len(qbuf), stream=streams[i])
+            r = wss[i].search_device(d_buf.data_ptr(), d_off.data_ptr(), args.queries, len(qbuf), stream=streams[i])
+            if args.post:
+                wss[i].topn_device(0.05, 10, 10, best_start_codon=reads, stream=streams[i])
+            return r
 
     for _ in range(args.warmup):
         step()
@@ -268,7 +276,7 @@ def main():
                                   else ("replicas x%d (no collective)" % world if world > 1 else "single GPU"),
                    "result": "device-resident per-query hit lists (offset, count, protein ids, Kmatch)" +
                              (", packed in query order" if args.compact else ""),
-                   "batches_in_flight": args.inflight,
+                   "batches_in_flight": args.inflight, "device_post_steps": bool(args.post),
                    "seed": workload.SEED},
         "query_seqs_per_s": queries_per_step * args.steps / elapsed,
         "counters_per_step_rank0": c,
@@ -279,7 +287,7 @@ def main():
         want_cpu = not args.no_cpu_baseline and world == 1 and not sharded_mode
         if sharded_mode:
             args.check = 0
-        if args.check or want_cpu:
+        if args.check or want_cpu or args.host_api:
             from oracle import oracle as O  # the checker / the reported CPU baseline, never the product
             t0 = time.time()
             oix = O.Index.from_proteins(None, packed=db)
@@ -319,6 +327,16 @@ def main():
                         assert res.hits(i) == exp, "bench: query %d differs from the oracle" % i
                 out["parity_checked_queries"] = len(sub)
                 log("parity: %d queries of the timed batch bit-exact vs oracle" % len(sub))
+            if args.host_api:
+                hb = {}
+                for name, fn in (("search_batch_top", lambda: ix.search_top(packed=q, seq_type=abi.READS if reads else abi.PROTEIN)),
+                                 ("search_batch", lambda: ix.search(packed=q, seq_type=abi.READS if reads else abi.PROTEIN))):
+                    fn()
+                    t0 = time.perf_counter()
+                    fn()
+                    hb[name] = {"ms": (time.perf_counter() - t0) * 1e3,
+                                "lookups_per_s": c["n_lookup"] / (time.perf_counter() - t0)}
+                out["host_buffer_calls_pcie_inclusive"] = hb
             if want_cpu:
                 out["cpu_baseline"] = cpu_baseline(oix, q, seconds=args.cpu_seconds, kind="reads" if reads else "protein")
         print(json.dumps(out), flush=True)

@@ -240,6 +240,58 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
 int kaamer_merge_device(kaamer_workspace *ws, const uint64_t *d_ent_off, const uint32_t *d_pid,
                         const uint32_t *d_kmatch, const uint32_t *d_first_pos, uint32_t n_queries,
                         uint64_t n_entries, void *stream, kaamer_device_result *out);
+/* Post-steps of the workspace's last search (or merge) on the device, one wave per
+ * query: sortMapByValue (search.go:132-152; ties by ascending protein id),
+ * for nucleotide/reads input SetBestStartCodon (dna.go:198-272) with its gate
+ * hits[0].Kmatch >= MinKMatch (search_fastq.go:119-123), then FilterResults
+ * (search.go:189-220).  Only the hits a caller returns leave the device:
+ * max_results entries per query instead of the full hit lists. */
+typedef struct {
+    double min_k_ratio;        /* SearchOptions.MinKRatio  (default 0.05)      */
+    int64_t min_k_match;       /* SearchOptions.MinKMatch  (default 10)        */
+    uint32_t max_results;      /* SearchOptions.MaxResults (default 10)        */
+    uint32_t best_start_codon; /* 1: SetBestStartCodon first (nucleotide/reads)*/
+    const int32_t *d_size_in_kmer; /* device, per query; NULL = the search's   */
+                               /* own queries; required after kaamer_merge_device */
+} kaamer_topn_opts;
+
+typedef struct {
+    uint32_t max_results;
+    const uint32_t *d_top_cnt;        /* per query: hits kept; 0 = not reported */
+    const uint32_t *d_top_pid;        /* [q * max_results + r], r < d_top_cnt[q], */
+    const uint32_t *d_top_kmatch;     /* in sortMapByValue order                */
+    const uint32_t *d_top_first_pos;
+    const int32_t *d_trim;            /* residues SetBestStartCodon removed     */
+    const int32_t *d_start_position;  /* Location.StartPosition afterwards      */
+    const int32_t *d_size_in_kmer;    /* Query.SizeInKmer afterwards            */
+} kaamer_topn_result;
+
+int kaamer_topn_device(kaamer_workspace *ws, const kaamer_topn_opts *opts, void *stream,
+                       kaamer_topn_result *out);
+/* Host-buffer call that returns what the reference's drivers report per query
+ * (search_protein.go:105-112, search_fastq.go:118-126): the hits that survive
+ * FilterResults, in sortMapByValue order, after SetBestStartCodon for nucleotide /
+ * reads input (best_start_codon is set from in->seq_type).  Only
+ * n_queries x max_results entries cross PCIe.  A query with top_cnt == 0 is not
+ * reported by the reference.  q[i] carries Location.StartPosition, SizeInKmer and the
+ * Sequence window (aa_off, aa_len) as they are after SetBestStartCodon. */
+typedef struct {
+    uint32_t n_queries;
+    uint32_t max_results;
+    const kaamer_query_meta *q;
+    const int32_t *trim;            /* residues removed from the ORF head      */
+    const uint32_t *top_cnt;
+    const uint32_t *top_pid;        /* [i * max_results + r], r < top_cnt[i]   */
+    const uint32_t *top_kmatch;
+    const uint32_t *top_first_pos;  /* relative to the untrimmed ORF           */
+    const uint8_t *orf_aa;          /* nucleotide / reads: ORF amino acids     */
+    kaamer_counters counters;
+} kaamer_batch_top;
+
+int kaamer_search_batch_top(kaamer_index *ix, const kaamer_batch_in *in, const kaamer_topn_opts *top,
+                            kaamer_batch_top **out);
+void kaamer_batch_top_free(kaamer_batch_top *out);
+
 /* Waits for `stream`, copies the counters to the host and reports a deferred
  * KAAMER_E_CAPACITY if a device-side bound was exceeded during the batch. */
 int kaamer_workspace_finish(kaamer_workspace *ws, void *stream, kaamer_counters *out);

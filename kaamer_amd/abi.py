@@ -77,6 +77,24 @@ class DeviceResult(C.Structure):
                 ("d_pos_base", C.c_void_p)]
 
 
+class TopnOpts(C.Structure):
+    _fields_ = [("min_k_ratio", C.c_double), ("min_k_match", C.c_int64), ("max_results", C.c_uint32),
+                ("best_start_codon", C.c_uint32), ("d_size_in_kmer", C.c_void_p)]
+
+
+class BatchTop(C.Structure):
+    _fields_ = [("n_queries", C.c_uint32), ("max_results", C.c_uint32), ("q", C.POINTER(QueryMeta)),
+                ("trim", C.POINTER(C.c_int32)), ("top_cnt", C.POINTER(C.c_uint32)), ("top_pid", C.POINTER(C.c_uint32)),
+                ("top_kmatch", C.POINTER(C.c_uint32)), ("top_first_pos", C.POINTER(C.c_uint32)),
+                ("orf_aa", C.POINTER(C.c_uint8)), ("counters", Counters)]
+
+
+class TopnResult(C.Structure):
+    _fields_ = [("max_results", C.c_uint32), ("d_top_cnt", C.c_void_p), ("d_top_pid", C.c_void_p),
+                ("d_top_kmatch", C.c_void_p), ("d_top_first_pos", C.c_void_p), ("d_trim", C.c_void_p),
+                ("d_start_position", C.c_void_p), ("d_size_in_kmer", C.c_void_p)]
+
+
 # every symbol include/kaamer_hip.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "kaamer_last_error": (C.c_char_p, []),
@@ -107,6 +125,9 @@ SYMBOLS = {
     "kaamer_workspace_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Counters)]),
     "kaamer_workspace_kernel_ms_sum": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                                  C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
+    "kaamer_topn_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "kaamer_search_batch_top": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "kaamer_batch_top_free": (None, [C.c_void_p]),
     "kaamer_workspace_reset_timers": (None, [C.c_void_p]),
     "kaamer_workspace_set_timing": (None, [C.c_void_p, C.c_uint32]),
     "kaamer_filter_results": (C.c_int64, [C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_int64, C.c_int64]),

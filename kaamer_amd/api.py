@@ -90,6 +90,31 @@ def build_image_from_proteins(seqs, ids=None, **kw):
     return Image.from_proteins(seqs, ids=ids, **kw)
 
 
+META_DTYPE = np.dtype([("src_seq", "<u4"), ("size_in_kmer", "<i4"), ("start_position", "<i4"), ("end_position", "<i4"),
+                       ("plus_strand", "<i4"), ("aa_len", "<u4"), ("aa_off", "<u8"), ("sa_off", "<u4"), ("sa_len", "<u4")])
+
+
+class TopResult:
+    """Host view of one kaamer_batch_top (copied out, the C object is freed)."""
+
+    def __init__(self, out):
+        o = out.contents
+        n, k = o.n_queries, o.max_results
+        self.n_queries, self.max_results = n, k
+        meta = np.ctypeslib.as_array(C.cast(o.q, C.POINTER(C.c_uint8)), shape=(n * C.sizeof(abi.QueryMeta),)).copy() \
+            if n else np.zeros(0, np.uint8)
+        self.meta = meta.view(META_DTYPE)
+        z = np.zeros(0, np.uint32)
+        self.trim = np.ctypeslib.as_array(o.trim, shape=(n,)).copy() if n else np.zeros(0, np.int32)
+        self.top_cnt = np.ctypeslib.as_array(o.top_cnt, shape=(n,)).copy() if n else z
+        self.top_pid = np.ctypeslib.as_array(o.top_pid, shape=(n * k,)).copy().reshape(n, k) if n else z.reshape(0, k)
+        self.top_kmatch = np.ctypeslib.as_array(o.top_kmatch, shape=(n * k,)).copy().reshape(n, k) if n else z.reshape(0, k)
+        self.top_first_pos = np.ctypeslib.as_array(o.top_first_pos, shape=(n * k,)).copy().reshape(n, k) if n else z.reshape(0, k)
+        aa_len = int((self.meta["aa_off"] + self.meta["aa_len"]).max()) if n and bool(o.orf_aa) else 0
+        self.orf_aa = np.ctypeslib.as_array(o.orf_aa, shape=(aa_len,)).copy() if aa_len else np.zeros(0, np.uint8)
+        self.counters = o.counters.as_dict()
+
+
 class BatchResult:
     """Host view of one kaamer_batch_out (copied out, the C object is freed)."""
 
@@ -189,6 +214,21 @@ class Index:
         finally:
             abi.lib().kaamer_batch_free(out)
 
+    def search_top(self, seqs=None, packed=None, seq_type=abi.PROTEIN, min_k_ratio=0.05, min_k_match=10, max_results=10):
+        """Host-buffer form that returns the reported hits only (kaamer_search_batch_top):
+        sortMapByValue order, SetBestStartCodon for nucleotide/reads, FilterResults -- all on the device."""
+        buf, offs = packed if packed is not None else pack_sequences(seqs)
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        bi = abi.BatchIn(buf.ctypes.data if len(buf) else None, offs.ctypes.data, len(offs) - 1, seq_type, 0)
+        to = abi.TopnOpts(min_k_ratio, min_k_match, max_results, 0, None)
+        out = C.POINTER(abi.BatchTop)()
+        abi.check(abi.lib().kaamer_search_batch_top(self._h, C.byref(bi), C.byref(to), C.byref(out)))
+        try:
+            return TopResult(out)
+        finally:
+            abi.lib().kaamer_batch_top_free(out)
+
     def close(self):
         if self._h:
             abi.lib().kaamer_index_close(self._h)
@@ -229,6 +269,14 @@ class Workspace:
         r = abi.DeviceResult()
         abi.check(abi.lib().kaamer_merge_device(self._h, d_ent_off_ptr, d_pid_ptr, d_km_ptr, d_fp_ptr, n_queries,
                                                 n_entries, C.c_void_p(stream), C.byref(r)))
+        return r
+
+    def topn_device(self, min_k_ratio=0.05, min_k_match=10, max_results=10, best_start_codon=False,
+                    d_size_in_kmer_ptr=None, stream=0):
+        """sortMapByValue + (SetBestStartCodon) + FilterResults of the last search/merge, on the device"""
+        o = abi.TopnOpts(min_k_ratio, min_k_match, max_results, int(best_start_codon), d_size_in_kmer_ptr)
+        r = abi.TopnResult()
+        abi.check(abi.lib().kaamer_topn_device(self._h, C.byref(o), C.c_void_p(stream), C.byref(r)))
         return r
 
     def finish(self, stream=0):

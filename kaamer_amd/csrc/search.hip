@@ -722,6 +722,7 @@ __global__ void prep_protein_kernel(const uint8_t *seqs, const uint64_t *offsets
 }
 
 #include "translate.hip.inc"
+#include "topn.hip.inc"
 
 // ------------------------------------------------------------------------------------
 // exclusive scan of q_cnt[0..nq) -> hit_off[0..nq]
@@ -904,6 +905,11 @@ struct kaamer_workspace {
     int32_t *d_starts_alt;
     uint32_t max_seqs;
     unsigned long long *d_chain;        // layout_kernel: one word per tile, tagged with the batch epoch
+    // post-steps (kaamer_topn_device), allocated on first use
+    uint32_t topn_k;
+    uint32_t *d_top_cnt, *d_top_pid, *d_top_km, *d_top_fp;
+    int32_t *d_top_trim, *d_top_start, *d_top_size;
+    bool last_was_merge;
     uint32_t lay_epoch;
     uint32_t *d_list_counts;            // [N_LISTS] + queue head + status (zeroed by finalize)
     uint32_t *d_status_out;             // status of the last finished batch
@@ -1009,7 +1015,7 @@ void kaamer_workspace_free(kaamer_workspace *ws)
                      ws->d_tmp_meta, ws->d_orf_aa, ws->d_starts_alt, ws->d_q_cnt, ws->d_csr_off, ws->d_c_pid, ws->d_c_km, ws->d_c_fp,
                      ws->d_pool_cursor, ws->d_lists, ws->d_list_counts, ws->d_status_out, ws->d_qinfo, ws->d_slots,
                      ws->d_slot_off, ws->d_group_first, ws->d_n_groups, ws->d_pos_words, ws->d_pos_base, ws->d_pos_off, ws->d_pos_bits, ws->d_g_keys,
-                     ws->d_g_cnt, ws->d_g_min, ws->d_counter_replicas, ws->d_counters, ws->d_bsum, ws->d_chain, ws->d_hit_off,
+                     ws->d_g_cnt, ws->d_g_min, ws->d_counter_replicas, ws->d_counters, ws->d_bsum, ws->d_chain, ws->d_top_cnt, ws->d_top_pid, ws->d_top_km, ws->d_top_fp, ws->d_top_trim, ws->d_top_start, ws->d_top_size, ws->d_hit_off,
                      ws->d_hit_pid, ws->d_hit_km, ws->d_hit_fp };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (ws->ev) {
@@ -1126,13 +1132,14 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     if (!rc) rc = dev_alloc(&ws->d_hit_pid, ws->sparse_cap);
     if (!rc) rc = dev_alloc(&ws->d_hit_km, ws->sparse_cap);
     if (!rc) rc = dev_alloc(&ws->d_hit_fp, ws->sparse_cap);
-    if (!rc && hipMemset(ws->d_hit_fp, 0, ws->sparse_cap * sizeof(uint32_t)) != hipSuccess) rc = kaamer_fail(KAAMER_E_HIP, "memset");
+    // first positions are written only when asked for; otherwise the array reads as zeros
+    if (!rc && !ws->firstpos && hipMemset(ws->d_hit_fp, 0, ws->sparse_cap * sizeof(uint32_t)) != hipSuccess) rc = kaamer_fail(KAAMER_E_HIP, "memset");
     if (!rc && ws->compact) {
         rc = dev_alloc(&ws->d_csr_off, (size_t)ws->q_cap + 1);
         if (!rc) rc = dev_alloc(&ws->d_c_pid, ws->hit_cap);
         if (!rc) rc = dev_alloc(&ws->d_c_km, ws->hit_cap);
         if (!rc) rc = dev_alloc(&ws->d_c_fp, ws->hit_cap);
-        if (!rc && hipMemset(ws->d_c_fp, 0, ws->hit_cap * sizeof(uint32_t)) != hipSuccess) rc = kaamer_fail(KAAMER_E_HIP, "memset");
+        if (!rc && !ws->firstpos && hipMemset(ws->d_c_fp, 0, ws->hit_cap * sizeof(uint32_t)) != hipSuccess) rc = kaamer_fail(KAAMER_E_HIP, "memset");
     }
     if (rc) { kaamer_workspace_free(ws); return rc; }
     ws->ev = new (std::nothrow) std::vector<hipEvent_t>();
@@ -1367,6 +1374,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     if (timed) HIPCHK(hipEventRecord(ev[4], s));
     HIPCHK(hipGetLastError());
     ws->clean = true;  // everything up to finalize is enqueued
+    ws->last_was_merge = false;
     if (timed) ws->n_timed++;
 
     out->n_queries_cap = ws->q_cap;
@@ -1442,11 +1450,72 @@ int kaamer_merge_device(kaamer_workspace *ws, const uint64_t *d_ent_off, const u
                        ws->d_status_out, ws->d_pool_cursor);
     HIPCHK(hipGetLastError());
     ws->clean = true;
+    ws->last_was_merge = true;
     memset(out, 0, sizeof *out);
     out->n_queries_cap = ws->q_cap;
     out->d_n_queries = ws->d_nq;
     fill_result_hits(ws, out);
     out->d_counters = ws->d_counters;
+    return KAAMER_OK;
+}
+
+// FilterResults / top-N (and SetBestStartCodon for nucleotide input) of the workspace's last
+// search or merge, on the device; see topn.hip.inc.
+int kaamer_topn_device(kaamer_workspace *ws, const kaamer_topn_opts *opts, void *stream, kaamer_topn_result *out)
+{
+    if (!ws || !opts || !out || opts->max_results < 1) return kaamer_fail(KAAMER_E_ARG, "topn_device: bad argument");
+    const bool best_start = opts->best_start_codon != 0;
+    if (best_start && (!ws->nucleotide || ws->last_was_merge))
+        return kaamer_fail(KAAMER_E_ARG, "topn_device: SetBestStartCodon needs the ORFs of a nucleotide/reads search");
+    if (ws->last_was_merge && !opts->d_size_in_kmer)
+        return kaamer_fail(KAAMER_E_ARG, "topn_device: merged results need d_size_in_kmer (the owner's queries)");
+    if (best_start && !ws->firstpos) return kaamer_fail(KAAMER_E_ARG, "topn_device: SetBestStartCodon needs first positions (first_pos != 2)");
+    HIPCHK(hipSetDevice(ws->device));
+    if (ws->topn_k < opts->max_results) {
+        uint32_t **bufs[] = { &ws->d_top_pid, &ws->d_top_km, &ws->d_top_fp };
+        for (uint32_t **b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
+        int rc = 0;
+        const size_t n = (size_t)ws->q_cap * opts->max_results;
+        rc = dev_alloc(&ws->d_top_pid, n);
+        if (!rc) rc = dev_alloc(&ws->d_top_km, n);
+        if (!rc) rc = dev_alloc(&ws->d_top_fp, n);
+        if (!rc && !ws->d_top_cnt) {
+            rc = dev_alloc(&ws->d_top_cnt, ws->q_cap);
+            if (!rc) rc = dev_alloc(&ws->d_top_trim, ws->q_cap);
+            if (!rc) rc = dev_alloc(&ws->d_top_start, ws->q_cap);
+            if (!rc) rc = dev_alloc(&ws->d_top_size, ws->q_cap);
+        }
+        if (rc) { ws->topn_k = 0; return rc; }
+        ws->topn_k = opts->max_results;
+    }
+    TopnParams p;
+    memset(&p, 0, sizeof p);
+    p.d_nq = ws->d_nq;
+    p.q = ws->d_q;
+    p.size_in = opts->d_size_in_kmer;
+    p.hit_cnt = ws->d_q_cnt;
+    p.hit_off = ws->compact ? ws->d_csr_off : ws->d_hit_off;
+    p.pid = ws->compact ? ws->d_c_pid : ws->d_hit_pid;
+    p.km = ws->compact ? ws->d_c_km : ws->d_hit_km;
+    p.fp = ws->compact ? ws->d_c_fp : ws->d_hit_fp;
+    p.orf_aa = ws->d_orf_aa;
+    p.starts_alt = ws->d_starts_alt;
+    p.min_k_ratio = opts->min_k_ratio;
+    p.min_k_match = opts->min_k_match;
+    p.K = opts->max_results;
+    p.best_start = best_start ? 1 : 0;
+    p.top_cnt = ws->d_top_cnt; p.top_pid = ws->d_top_pid; p.top_km = ws->d_top_km; p.top_fp = ws->d_top_fp;
+    p.trim = ws->d_top_trim; p.start_pos = ws->d_top_start; p.size_out = ws->d_top_size;
+    hipLaunchKernelGGL(topn_kernel, dim3(ws->n_cu * 8), dim3(256), 0, (hipStream_t)stream, p);
+    HIPCHK(hipGetLastError());
+    out->max_results = opts->max_results;
+    out->d_top_cnt = ws->d_top_cnt;
+    out->d_top_pid = ws->d_top_pid;
+    out->d_top_kmatch = ws->d_top_km;
+    out->d_top_first_pos = ws->d_top_fp;
+    out->d_trim = ws->d_top_trim;
+    out->d_start_position = ws->d_top_start;
+    out->d_size_in_kmer = ws->d_top_size;
     return KAAMER_OK;
 }
 
@@ -1635,6 +1704,136 @@ int kaamer_search_batch(kaamer_index *ix, const kaamer_batch_in *in, kaamer_batc
             max_queries = (uint32_t)(hard > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : hard);
         }
     }
+}
+
+// ---- host-buffer form that returns what a caller reports: the filtered top hits only ----------
+struct batch_top_owner {
+    kaamer_batch_top pub;
+    std::vector<kaamer_query_meta> q;
+    std::vector<int32_t> trim;
+    std::vector<uint32_t> cnt, pid, km, fp;
+    std::vector<uint8_t> orf_aa;
+};
+
+static int search_batch_top_once(kaamer_index *ix, const kaamer_batch_in *in, const kaamer_topn_opts *top, uint64_t max_hits,
+                                 uint64_t g_slots, uint32_t max_queries, kaamer_batch_top **out)
+{
+    const uint64_t seq_bytes = in->offsets[in->n_seqs];
+    const bool nucl = in->seq_type == KAAMER_NUCLEOTIDE || in->seq_type == KAAMER_READS;
+    kaamer_workspace_opts o;
+    memset(&o, 0, sizeof o);
+    o.max_seq_bytes = seq_bytes;
+    o.max_seqs = in->n_seqs ? in->n_seqs : 1;
+    o.max_hits = max_hits;
+    o.g_tier_slots = g_slots;
+    o.seq_type = in->seq_type;
+    o.first_pos = 1;
+    o.max_queries = max_queries;
+    kaamer_workspace *ws = nullptr;
+    int rc = kaamer_workspace_create(ix, &o, &ws);
+    if (rc) return rc;
+    uint8_t *d_seqs = nullptr;
+    uint64_t *d_off = nullptr;
+    batch_top_owner *bo = nullptr;
+    hipStream_t s = nullptr;
+    kaamer_device_result dr;
+    kaamer_topn_result tr;
+    kaamer_topn_opts t = *top;
+    kaamer_counters c;
+    uint32_t nq = 0;
+    hipError_t e;
+    t.best_start_codon = nucl ? 1u : 0u;  // search_fastq.go:121, search_nucleotide.go:118; not in search_protein.go
+    t.d_size_in_kmer = nullptr;
+    rc = dev_alloc(&d_seqs, (size_t)seq_bytes + 16);
+    if (!rc) rc = dev_alloc(&d_off, (size_t)in->n_seqs + 1);
+    if (rc) goto done;
+    e = hipMemcpyAsync(d_seqs, in->seqs, (size_t)seq_bytes, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_off, in->offsets, ((size_t)in->n_seqs + 1) * 8, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) { rc = kaamer_fail(KAAMER_E_HIP, "H2D: %s", hipGetErrorString(e)); goto done; }
+    rc = kaamer_search_device(ix, ws, d_seqs, d_off, in->n_seqs, seq_bytes, in->seq_type, s, &dr);
+    if (!rc) rc = kaamer_topn_device(ws, &t, s, &tr);
+    if (!rc) rc = kaamer_workspace_finish(ws, s, &c);
+    if (rc) goto done;
+    bo = new (std::nothrow) batch_top_owner();
+    if (!bo) { rc = kaamer_fail(KAAMER_E_NOMEM, "batch_top"); goto done; }
+    e = hipMemcpy(&nq, dr.d_n_queries, 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) {
+        const size_t nk = (size_t)nq * t.max_results;
+        bo->q.resize((size_t)nq + 1); bo->trim.resize((size_t)nq + 1); bo->cnt.resize((size_t)nq + 1);
+        bo->pid.resize(nk + 1); bo->km.resize(nk + 1); bo->fp.resize(nk + 1);
+        if (nq) {
+            std::vector<int32_t> sp(nq), sz(nq);
+            e = hipMemcpy(bo->q.data(), dr.d_q, (size_t)nq * sizeof(kaamer_query_meta), hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(bo->trim.data(), tr.d_trim, (size_t)nq * 4, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(sp.data(), tr.d_start_position, (size_t)nq * 4, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(sz.data(), tr.d_size_in_kmer, (size_t)nq * 4, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(bo->cnt.data(), tr.d_top_cnt, (size_t)nq * 4, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(bo->pid.data(), tr.d_top_pid, nk * 4, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(bo->km.data(), tr.d_top_kmatch, nk * 4, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(bo->fp.data(), tr.d_top_first_pos, nk * 4, hipMemcpyDeviceToHost);
+            // the query as the reference reports it after SetBestStartCodon (dna.go:252-267)
+            for (uint32_t i = 0; e == hipSuccess && i < nq; i++) {
+                kaamer_query_meta &m = bo->q[i];
+                m.start_position = sp[i];
+                m.size_in_kmer = sz[i];
+                m.aa_off += (uint64_t)bo->trim[i];
+                m.aa_len -= (uint32_t)bo->trim[i];
+            }
+        }
+    }
+    if (e == hipSuccess && nucl) {
+        unsigned long long n_aa = 0;
+        e = hipMemcpy(&n_aa, ws->d_n_pos, sizeof n_aa, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) bo->orf_aa.resize(n_aa + 1);
+        if (e == hipSuccess && n_aa) e = hipMemcpy(bo->orf_aa.data(), dr.d_orf_aa, n_aa, hipMemcpyDeviceToHost);
+    }
+    if (e != hipSuccess) { rc = kaamer_fail(KAAMER_E_HIP, "D2H: %s", hipGetErrorString(e)); goto done; }
+    memset(&bo->pub, 0, sizeof bo->pub);
+    bo->pub.n_queries = nq;
+    bo->pub.max_results = t.max_results;
+    bo->pub.q = bo->q.data();
+    bo->pub.trim = bo->trim.data();
+    bo->pub.top_cnt = bo->cnt.data();
+    bo->pub.top_pid = bo->pid.data();
+    bo->pub.top_kmatch = bo->km.data();
+    bo->pub.top_first_pos = bo->fp.data();
+    if (nucl) bo->pub.orf_aa = bo->orf_aa.data();
+    bo->pub.counters = c;
+    *out = &bo->pub;
+    bo = nullptr;
+done:
+    delete bo;
+    if (d_seqs) (void)hipFree(d_seqs);
+    if (d_off) (void)hipFree(d_off);
+    kaamer_workspace_free(ws);
+    return rc;
+}
+
+int kaamer_search_batch_top(kaamer_index *ix, const kaamer_batch_in *in, const kaamer_topn_opts *top, kaamer_batch_top **out)
+{
+    if (!ix || !in || !top || !out || !in->offsets || (in->n_seqs && !in->seqs) || top->max_results < 1)
+        return kaamer_fail(KAAMER_E_ARG, "search_batch_top: bad argument");
+    *out = nullptr;
+    HIPCHK(hipSetDevice(ix->device));
+    uint64_t max_hits = 0, g_slots = 0;  // the device form derives the hit arrays from the batch size; only the G tier can run out
+    uint32_t max_queries = 0;
+    const bool nucl = in->seq_type == KAAMER_NUCLEOTIDE || in->seq_type == KAAMER_READS;
+    for (int attempt = 0;; attempt++) {
+        const int rc = search_batch_top_once(ix, in, top, max_hits, g_slots, max_queries, out);
+        if (rc != KAAMER_E_CAPACITY || attempt >= 6) return rc;
+        max_hits = max_hits ? max_hits * 4 : in->offsets[in->n_seqs] * 8 + 65536;
+        g_slots = g_slots ? g_slots * 4 : (128ull << 20);
+        if (nucl) {
+            const uint64_t hard = in->offsets[in->n_seqs] / 10 + (uint64_t)in->n_seqs * 6 + 64;
+            max_queries = (uint32_t)(hard > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : hard);
+        }
+    }
+}
+
+void kaamer_batch_top_free(kaamer_batch_top *out)
+{
+    if (!out) return;
+    delete reinterpret_cast<batch_top_owner *>(out);  // pub is the first member
 }
 
 void kaamer_batch_free(kaamer_batch_out *out)

@@ -1,8 +1,10 @@
 """Host-side mirror of the reference's search drivers (pkg/search/search_protein.go,
 search_fastq.go, search_nucleotide.go) over the C ABI: same option names and defaults
 (api/server.go:139-152), same per-query flow, results as plain dicts shaped like the
-reference's JSON (docs/client.md:131-180).  All compute is in libkaamer_hip.so:
-readers, k-mer search, sort, FilterResults and SetBestStartCodon are C-ABI calls.
+reference's JSON (docs/client.md:131-180).  All compute is in libkaamer_hip.so: readers and
+k-mer search; sortMapByValue, SetBestStartCodon and FilterResults run on the device
+(kaamer_search_batch_top) unless ExtractPositions asks for the full hit lists + bitmaps, in
+which case the host versions of the same C ABI are used.
 """
 import ctypes as C
 from dataclasses import dataclass
@@ -43,6 +45,21 @@ def ProteinSearch(index, fasta_text, options=None):
     """search_protein.go:27-134 for one FASTA upload -> list of QueryResult dicts"""
     o = options or SearchOptions(SequenceType=abi.PROTEIN)
     queries = api.parse_reads(fasta_text, "fasta")
+    if not o.ExtractPositions:
+        # sortMapByValue + FilterResults on the device: only the reported hits come back
+        top = index.search_top([q["seq"] for q in queries], seq_type=abi.PROTEIN, min_k_ratio=o.MinKRatio,
+                               min_k_match=o.MinKMatch, max_results=o.MaxResults)
+        out = []
+        for i, q in enumerate(queries):
+            keep = int(top.top_cnt[i])
+            if q["size"] < 7 or keep == 0:  # search_protein.go:74-76, :108
+                continue
+            out.append({"Query": {"Sequence": q["seq"], "Name": q["name"], "SizeInKmer": q["size"], "Type": PROTEIN_QUERY,
+                                  "Location": {"StartPosition": 1, "EndPosition": len(q["seq"]), "PlusStrand": True,
+                                               "StartsAlternative": []}, "Contig": ""},
+                        "SearchResults": {"Hits": [{"Key": int(p), "Kmatch": int(k)}
+                                                   for p, k in zip(top.top_pid[i, :keep], top.top_kmatch[i, :keep])]}})
+        return out
     res = index.search([q["seq"] for q in queries], seq_type=abi.PROTEIN, want_positions=o.ExtractPositions)
     out = []
     for i, q in enumerate(queries):
@@ -64,6 +81,25 @@ def ProteinSearch(index, fasta_text, options=None):
 
 
 def _orf_results(index, reads, names, o, seq_type):
+    if not o.ExtractPositions:
+        # SetBestStartCodon, its gate and FilterResults on the device (kaamer_search_batch_top)
+        top = index.search_top(reads, seq_type=seq_type, min_k_ratio=o.MinKRatio, min_k_match=o.MinKMatch,
+                               max_results=o.MaxResults)
+        out = []
+        for i in range(top.n_queries):
+            keep = int(top.top_cnt[i])
+            if keep == 0:
+                continue
+            m = top.meta[i]
+            aa = bytes(top.orf_aa[int(m["aa_off"]):int(m["aa_off"]) + int(m["aa_len"])])  # already trimmed
+            out.append({"Query": {"Sequence": aa.decode("latin-1"), "Name": names[int(m["src_seq"])],
+                                  "SizeInKmer": int(m["size_in_kmer"]), "Type": DNA_QUERY,
+                                  "Location": {"StartPosition": int(m["start_position"]), "EndPosition": int(m["end_position"]),
+                                               "PlusStrand": bool(m["plus_strand"]), "StartsAlternative": []},
+                                  "Contig": ""},
+                        "SearchResults": {"Hits": [{"Key": int(p), "Kmatch": int(k)}
+                                                   for p, k in zip(top.top_pid[i, :keep], top.top_kmatch[i, :keep])]}})
+        return out
     res = index.search(reads, seq_type=seq_type, want_positions=o.ExtractPositions)
     out = []
     for i in range(res.n_queries):
