@@ -1245,7 +1245,10 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         int tgrid = ws->n_cu * 8;  // 256-thread blocks, one (sequence, frame) item per wave at a time
         if ((uint64_t)tgrid * 4 > n6) tgrid = n6 > 0 ? (int)((n6 + 3) / 4) : 1;
         tp.d_n6 = ws->d_n6;
+        int sgrid = ws->n_cu * 5;  // lane-per-read kernel: 2-wave blocks, ~31 KB of LDS each
+        if ((uint64_t)sgrid * TS_WAVES * 64 > (uint64_t)n_seqs) sgrid = n_seqs > 0 ? (int)(((uint64_t)n_seqs + TS_WAVES * 64 - 1) / (TS_WAVES * 64)) : 1;
         hipLaunchKernelGGL(translate_kernel<false>, dim3(tgrid), dim3(256), 0, s, tp);
+        hipLaunchKernelGGL(translate_short_kernel<false>, dim3(sgrid), dim3(64 * TS_WAVES), 0, s, tp);
         const uint32_t nsb6 = (uint32_t)((n6 + 1 + SCAN_TILE - 1) / SCAN_TILE);
         for (int a = 0; a < 3; a++) {
             const uint32_t *cnt = ws->d_cnt3 + a * cap6;
@@ -1259,6 +1262,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
             }
         }
         hipLaunchKernelGGL(translate_kernel<true>, dim3(tgrid), dim3(256), 0, s, tp);
+        hipLaunchKernelGGL(translate_short_kernel<true>, dim3(sgrid), dim3(64 * TS_WAVES), 0, s, tp);
         hipLaunchKernelGGL(orf_order_kernel, dim3(ws->n_cu * 4), dim3(256), 0, s, ws->d_tmp_meta, tp.off_orf, n_seqs, ws->d_q,
                            ws->d_nq, ws->d_n_pos, tp.off_aa, (uint64_t)ws->q_cap, status);
         hipLaunchKernelGGL(prep_orf_kernel, dim3(ws->n_cu * 4), dim3(pb), 0, s, ws->d_q, ws->d_nq, ws->d_valid, ws->d_n_pos,
