@@ -77,7 +77,7 @@ static_assert(sizeof(kaamer_counters) == CTR_N * 8, "counter layout");
 enum { LIST_S = 0, LIST_L, LIST_SO, LIST_G, N_LISTS };
 // small per-batch device state after the list counters (all zeroed by the finalize step)
 enum { SLOT_QUEUE_HEAD = N_LISTS, SLOT_STATUS = N_LISTS + 1, SLOT_GROUP_QUEUE = N_LISTS + 2, SLOT_GROUP_QUEUE_POS = N_LISTS + 3,
-       N_SMALL_SLOTS = N_LISTS + 4 };
+       SLOT_N_LONG = N_LISTS + 4, N_SMALL_SLOTS = N_LISTS + 5 };
 // one entry: everything a tier needs to start on a query, in one 16-byte load
 struct alignas(16) WorkItem {
     uint32_t q;
@@ -1247,8 +1247,9 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         tp.d_n6 = ws->d_n6;
         int sgrid = ws->n_cu * 5;  // lane-per-read kernel: 2-wave blocks, ~31 KB of LDS each
         if ((uint64_t)sgrid * TS_WAVES * 64 > (uint64_t)n_seqs) sgrid = n_seqs > 0 ? (int)(((uint64_t)n_seqs + TS_WAVES * 64 - 1) / (TS_WAVES * 64)) : 1;
-        hipLaunchKernelGGL(translate_kernel<false>, dim3(tgrid), dim3(256), 0, s, tp);
+        tp.n_long = ws->d_list_counts + SLOT_N_LONG;
         hipLaunchKernelGGL(translate_short_kernel<false>, dim3(sgrid), dim3(64 * TS_WAVES), 0, s, tp);
+        hipLaunchKernelGGL(translate_kernel<false>, dim3(tgrid), dim3(256), 0, s, tp);
         const uint32_t nsb6 = (uint32_t)((n6 + 1 + SCAN_TILE - 1) / SCAN_TILE);
         for (int a = 0; a < 3; a++) {
             const uint32_t *cnt = ws->d_cnt3 + a * cap6;
