@@ -261,7 +261,8 @@ def main():
                 "count_kernels": {"ms": count_s * 1e3, "algorithmic_bytes": count_bytes,
                                   "achieved_GBps": count_bytes / count_s / 1e9 if count_s > 0 else 0.0},
                 "whole_batch": {"ms": tm["total_ms"] / n_calls,
-                                "achieved_GBps": (probe_bytes + count_bytes) / (tm["total_ms"] / n_calls / 1e3) / 1e9}}
+                                "achieved_GBps": (probe_bytes + count_bytes) / (tm["total_ms"] / n_calls / 1e3) / 1e9
+                                if tm["total_ms"] > 0 else 0.0}}
 
     out = {
         "metric": "k-mer lookups/sec", "value": lookups_per_step * args.steps / elapsed,
