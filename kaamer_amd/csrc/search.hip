@@ -31,6 +31,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -60,11 +61,24 @@ int kaamer_fail(int code, const char *fmt, ...)
 // ------------------------------------------------------------------------------------
 // device-side structures
 // ------------------------------------------------------------------------------------
+struct kaamer_workspace;
+// the host-buffer calls keep their workspace and device staging buffers between calls
+// (creating and freeing ~1 GB of device memory per call cost 10x the search itself)
+struct HostSlot {
+    kaamer_workspace *ws = nullptr;
+    kaamer_workspace_opts opts{};
+    uint8_t *d_seqs = nullptr;
+    uint64_t *d_off = nullptr;
+    size_t seq_cap = 0, off_cap = 0;
+};
+
 struct kaamer_index {
     int device;
     kh_image_header hdr;
     kh_bucket *d_buckets;
     uint32_t *d_arena;
+    std::mutex host_mu;   // host-buffer calls on one index are serialised
+    HostSlot host[2];     // [0] kaamer_search_batch, [1] kaamer_search_batch_top
 };
 
 enum { ST_POOL_FULL = 1u, ST_LIST_FULL = 2u, ST_QUERY_CAP = 4u, ST_AA_CAP = 8u, ST_G_ARENA_FULL = 16u, ST_G_TABLE_FULL = 32u,
@@ -995,6 +1009,11 @@ void kaamer_index_close(kaamer_index *ix)
 {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
+    for (HostSlot &h : ix->host) {
+        if (h.ws) kaamer_workspace_free(h.ws);
+        if (h.d_seqs) (void)hipFree(h.d_seqs);
+        if (h.d_off) (void)hipFree(h.d_off);
+    }
     if (ix->d_buckets) (void)hipFree(ix->d_buckets);
     if (ix->d_arena) (void)hipFree(ix->d_arena);
     delete ix;
@@ -1596,6 +1615,44 @@ struct batch_out_owner {
     std::vector<uint64_t> pos_off, pos_bits;
 };
 
+// workspace + staging buffers of a host-buffer call: reused while they are large enough
+static int host_slot_acquire(kaamer_index *ix, HostSlot &h, const kaamer_workspace_opts &need, uint64_t seq_bytes, uint32_t n_seqs)
+{
+    const kaamer_workspace_opts &o = h.opts;
+    const bool fits = h.ws && o.seq_type == need.seq_type && o.first_pos == need.first_pos && o.want_positions == need.want_positions &&
+                      o.compact == need.compact && o.max_seq_bytes >= need.max_seq_bytes && o.max_seqs >= need.max_seqs &&
+                      o.max_hits >= need.max_hits && o.g_tier_slots >= need.g_tier_slots && o.max_queries >= need.max_queries &&
+                      o.max_pos_words >= need.max_pos_words && (need.max_hits != 0 || o.max_hits == 0);
+    if (!fits) {
+        if (h.ws) { kaamer_workspace_free(h.ws); h.ws = nullptr; }
+        kaamer_workspace_opts g = need;  // some headroom so that slightly larger batches do not rebuild it
+        g.max_seq_bytes = need.max_seq_bytes + need.max_seq_bytes / 4 + 4096;
+        g.max_seqs = need.max_seqs + need.max_seqs / 4 + 16;
+        if (need.max_hits) g.max_hits = need.max_hits + need.max_hits / 4;
+        if (need.max_pos_words) g.max_pos_words = need.max_pos_words + need.max_pos_words / 4;
+        const int rc = kaamer_workspace_create(ix, &g, &h.ws);
+        if (rc) { h.ws = nullptr; return rc; }
+        h.opts = g;
+    }
+    if (h.seq_cap < seq_bytes + 16) {
+        if (h.d_seqs) (void)hipFree(h.d_seqs);
+        h.d_seqs = nullptr; h.seq_cap = 0;
+        const size_t cap = (size_t)seq_bytes + (size_t)seq_bytes / 4 + 4096;
+        const int rc = dev_alloc(&h.d_seqs, cap);
+        if (rc) return rc;
+        h.seq_cap = cap;
+    }
+    if (h.off_cap < (size_t)n_seqs + 1) {
+        if (h.d_off) (void)hipFree(h.d_off);
+        h.d_off = nullptr; h.off_cap = 0;
+        const size_t cap = (size_t)n_seqs + (size_t)n_seqs / 4 + 16;
+        const int rc = dev_alloc(&h.d_off, cap);
+        if (rc) return rc;
+        h.off_cap = cap;
+    }
+    return KAAMER_OK;
+}
+
 static int search_batch_once(kaamer_index *ix, const kaamer_batch_in *in, uint64_t max_hits, uint64_t g_slots,
                              uint32_t max_queries, kaamer_batch_out **out)
 {
@@ -1612,11 +1669,12 @@ static int search_batch_once(kaamer_index *ix, const kaamer_batch_in *in, uint64
     o.compact = 1u;  // the host form is CSR
     o.max_pos_words = max_hits * 8;
     o.max_queries = max_queries;
-    kaamer_workspace *ws = nullptr;
-    int rc = kaamer_workspace_create(ix, &o, &ws);
+    HostSlot &slot = ix->host[0];
+    int rc = host_slot_acquire(ix, slot, o, seq_bytes, in->n_seqs);
     if (rc) return rc;
-    uint8_t *d_seqs = nullptr;
-    uint64_t *d_off = nullptr;
+    kaamer_workspace *ws = slot.ws;
+    uint8_t *d_seqs = slot.d_seqs;
+    uint64_t *d_off = slot.d_off;
     batch_out_owner *bo = nullptr;
     hipStream_t s = nullptr;
     kaamer_device_result dr;
@@ -1624,9 +1682,6 @@ static int search_batch_once(kaamer_index *ix, const kaamer_batch_in *in, uint64
     uint32_t nq = 0;
     uint64_t n_hits = 0;
     hipError_t e;
-    rc = dev_alloc(&d_seqs, (size_t)seq_bytes + 16);
-    if (!rc) rc = dev_alloc(&d_off, (size_t)in->n_seqs + 1);
-    if (rc) goto done;
     e = hipMemcpyAsync(d_seqs, in->seqs, (size_t)seq_bytes, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(d_off, in->offsets, ((size_t)in->n_seqs + 1) * 8, hipMemcpyHostToDevice, s);
     if (e != hipSuccess) { rc = kaamer_fail(KAAMER_E_HIP, "H2D: %s", hipGetErrorString(e)); goto done; }
@@ -1683,9 +1738,6 @@ static int search_batch_once(kaamer_index *ix, const kaamer_batch_in *in, uint64
     bo = nullptr;
 done:
     delete bo;
-    if (d_seqs) (void)hipFree(d_seqs);
-    if (d_off) (void)hipFree(d_off);
-    kaamer_workspace_free(ws);
     return rc;
 }
 
@@ -1693,6 +1745,7 @@ int kaamer_search_batch(kaamer_index *ix, const kaamer_batch_in *in, kaamer_batc
 {
     if (!ix || !in || !out || !in->offsets || (in->n_seqs && !in->seqs)) return kaamer_fail(KAAMER_E_ARG, "search_batch: bad argument");
     *out = nullptr;
+    std::lock_guard<std::mutex> lock(ix->host_mu);
     HIPCHK(hipSetDevice(ix->device));
     // The hit count of a batch is data dependent: start from a generous estimate and
     // enlarge on KAAMER_E_CAPACITY (the device reports it; results are never partial).
@@ -1734,11 +1787,12 @@ static int search_batch_top_once(kaamer_index *ix, const kaamer_batch_in *in, co
     o.seq_type = in->seq_type;
     o.first_pos = 1;
     o.max_queries = max_queries;
-    kaamer_workspace *ws = nullptr;
-    int rc = kaamer_workspace_create(ix, &o, &ws);
+    HostSlot &slot = ix->host[1];
+    int rc = host_slot_acquire(ix, slot, o, seq_bytes, in->n_seqs);
     if (rc) return rc;
-    uint8_t *d_seqs = nullptr;
-    uint64_t *d_off = nullptr;
+    kaamer_workspace *ws = slot.ws;
+    uint8_t *d_seqs = slot.d_seqs;
+    uint64_t *d_off = slot.d_off;
     batch_top_owner *bo = nullptr;
     hipStream_t s = nullptr;
     kaamer_device_result dr;
@@ -1749,9 +1803,6 @@ static int search_batch_top_once(kaamer_index *ix, const kaamer_batch_in *in, co
     hipError_t e;
     t.best_start_codon = nucl ? 1u : 0u;  // search_fastq.go:121, search_nucleotide.go:118; not in search_protein.go
     t.d_size_in_kmer = nullptr;
-    rc = dev_alloc(&d_seqs, (size_t)seq_bytes + 16);
-    if (!rc) rc = dev_alloc(&d_off, (size_t)in->n_seqs + 1);
-    if (rc) goto done;
     e = hipMemcpyAsync(d_seqs, in->seqs, (size_t)seq_bytes, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(d_off, in->offsets, ((size_t)in->n_seqs + 1) * 8, hipMemcpyHostToDevice, s);
     if (e != hipSuccess) { rc = kaamer_fail(KAAMER_E_HIP, "H2D: %s", hipGetErrorString(e)); goto done; }
@@ -1808,9 +1859,6 @@ static int search_batch_top_once(kaamer_index *ix, const kaamer_batch_in *in, co
     bo = nullptr;
 done:
     delete bo;
-    if (d_seqs) (void)hipFree(d_seqs);
-    if (d_off) (void)hipFree(d_off);
-    kaamer_workspace_free(ws);
     return rc;
 }
 
@@ -1819,6 +1867,7 @@ int kaamer_search_batch_top(kaamer_index *ix, const kaamer_batch_in *in, const k
     if (!ix || !in || !top || !out || !in->offsets || (in->n_seqs && !in->seqs) || top->max_results < 1)
         return kaamer_fail(KAAMER_E_ARG, "search_batch_top: bad argument");
     *out = nullptr;
+    std::lock_guard<std::mutex> lock(ix->host_mu);
     HIPCHK(hipSetDevice(ix->device));
     uint64_t max_hits = 0, g_slots = 0;  // the device form derives the hit arrays from the batch size; only the G tier can run out
     uint32_t max_queries = 0;
