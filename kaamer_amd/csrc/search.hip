@@ -562,7 +562,7 @@ __device__ __forceinline__ void finalize_body(unsigned long long *replicas, kaam
         *status_out = IN_FLIGHT ? __hip_atomic_load(&small_state[SLOT_STATUS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : small_state[SLOT_STATUS];
     __syncthreads();
     if (threadIdx.x < N_SMALL_SLOTS) small_state[threadIdx.x] = 0;
-    if (threadIdx.x < 2) cursors[threadIdx.x * CURSOR_STRIDE] = 0;  // G-tier tail cursor, G arena cursor
+    if (threadIdx.x < 3) cursors[threadIdx.x * CURSOR_STRIDE] = 0;  // G-tier tail cursor, G arena cursors (count, positions)
 }
 
 __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams p)
@@ -671,6 +671,88 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
         if (s_last) {
             finalize_body<true>(p.counters, p.fin_out, p.fin_small, p.fin_status_out, p.fin_cursors);
         }
+    }
+}
+
+// PositionHits of the G-tier queries (search.go:442-452): the query's final hit list goes into a
+// table in HBM (id -> index in the list), then every (position, id) sets one bit of that hit's bitmap.
+struct BitsTable {
+    const uint32_t *keys, *idx;
+    uint32_t *nd;
+    uint32_t log2cap, words;
+    unsigned long long *bits;  // first bitmap of the query
+    __device__ __forceinline__ bool add_n(uint32_t pid, uint32_t pos, uint32_t n, uint32_t &) const
+    {
+        const uint32_t mask = (1u << log2cap) - 1u;
+        uint32_t h = (pid * 0x9E3779B1u) >> (32 - log2cap);
+        for (uint32_t t = 0; t <= mask; t++) {
+            const uint32_t k = __hip_atomic_load(&keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (k == pid) {
+                unsigned long long *bm = bits + (unsigned long long)__hip_atomic_load(&idx[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * words;
+                const uint32_t w0 = pos >> 6, b0 = pos & 63u;
+                const uint32_t n0 = n < 64u - b0 ? n : 64u - b0;
+                atomicOr(&bm[w0], (n0 == 64u ? ~0ull : ((1ull << n0) - 1ull)) << b0);
+                if (n > n0) atomicOr(&bm[w0 + 1], (1ull << (n - n0)) - 1ull);
+                return true;
+            }
+            if (k == KH_EMPTY_PID) return false;  // cannot happen: every id of the postings is a hit
+            h = (h + 1u) & mask;
+        }
+        return false;
+    }
+    __device__ __forceinline__ bool over_limit() const { return false; }
+};
+
+__global__ __launch_bounds__(64 * G_WAVES) void positions_global_kernel(CountParams p)
+{
+    constexpr int WAVES = G_WAVES;
+    constexpr int NWIN = 2;
+    __shared__ uint32_t s_nd;
+    __shared__ uint32_t s_pref[WAVES][NWIN * 64];
+    __shared__ unsigned long long s_off;
+    const uint32_t tid = threadIdx.x, wv = tid >> 6;
+    const uint32_t n_items = *p.list_count < p.list_cap ? *p.list_count : p.list_cap;
+    PostCtr pc;
+    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+        const WorkItem wi = p.list[item];
+        const uint32_t q = wi.q, cnt = p.q_cnt[q];
+        const int32_t size = wi.size;
+        const unsigned long long hoff = p.hit_off[q];
+        uint32_t log2cap = 10;
+        while ((1ull << log2cap) < 2ull * cnt && log2cap < 31) log2cap++;
+        const unsigned long long cap = 1ull << log2cap;
+        if (tid == 0) {
+            s_nd = 0;
+            const unsigned long long off = atomicAdd(p.g_cursor, cap);
+            if (off + cap > p.g_slots) { atomicOr(p.status, (uint32_t)ST_G_ARENA_FULL); s_off = ~0ull; }
+            else s_off = off;
+        }
+        __syncthreads();
+        const unsigned long long off = s_off;
+        if (off == ~0ull || cnt == 0 || size <= 0) { __syncthreads(); continue; }
+        uint32_t *keys = p.g_keys + off, *idx = p.g_cnt + off;
+        for (unsigned long long i = tid; i < cap; i += 64 * WAVES) keys[i] = KH_EMPTY_PID;
+        __threadfence();
+        __syncthreads();
+        const uint32_t mask = (uint32_t)cap - 1u;
+        for (uint32_t i = tid; i < cnt; i += 64 * WAVES) {
+            const uint32_t pid = p.hit_pid[hoff + i];
+            uint32_t h = (pid * 0x9E3779B1u) >> (32 - log2cap);
+            while (atomicCAS(&keys[h], KH_EMPTY_PID, pid) != KH_EMPTY_PID) h = (h + 1u) & mask;  // ids are distinct, load <= 0.5
+            idx[h] = i;
+        }
+        __threadfence();
+        __syncthreads();
+        BitsTable bt;
+        bt.keys = keys; bt.idx = idx; bt.nd = &s_nd; bt.log2cap = log2cap;
+        bt.words = ((uint32_t)size + 63u) >> 6;
+        bt.bits = p.pos_bits + p.pos_base[q];
+        pc.clear();
+        bool ok = true;
+        for (int32_t r0 = 0; r0 < size; r0 += 64 * WAVES * NWIN)
+            ok = count_windows<BitsTable, NWIN, false>(p, p.vals + wi.aa_off, size, r0 + 64 * (int32_t)wv, 64 * WAVES, bt, pc, s_pref[wv]) && ok;
+        if (!ok && (tid & 63u) == 0) atomicOr(p.status, (uint32_t)ST_G_TABLE_FULL);
+        __syncthreads();
     }
 }
 
@@ -899,7 +981,7 @@ struct kaamer_workspace {
     unsigned long long *d_valid;        // one bit per residue position
     uint32_t *d_vals;                   // probe result per residue position
     uint32_t *d_q_cnt;
-    unsigned long long *d_pool_cursor;  // [0] G-tier tail cursor, [CURSOR_STRIDE] G arena cursor
+    unsigned long long *d_pool_cursor;  // CURSOR_STRIDE apart: G-tier tail cursor, G arena cursor (count), G arena cursor (positions)
     WorkItem *d_lists;                  // [N_LISTS][q_cap] (only the G tier's overflow list is used)
     QInfo *d_qinfo;
     uint32_t *d_slots;
@@ -1120,7 +1202,7 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
         if (!rc) rc = dev_alloc(&ws->d_starts_alt, (size_t)ws->sa_cap + 64);
     }
     if (!rc) rc = dev_alloc(&ws->d_q_cnt, ws->q_cap);
-    if (!rc) rc = dev_alloc(&ws->d_pool_cursor, (size_t)2 * CURSOR_STRIDE);
+    if (!rc) rc = dev_alloc(&ws->d_pool_cursor, (size_t)3 * CURSOR_STRIDE);
     if (!rc) rc = dev_alloc(&ws->d_lists, (size_t)N_LISTS * ws->q_cap);
     if (!rc) rc = dev_alloc(&ws->d_list_counts, N_SMALL_SLOTS);
     if (!rc) rc = dev_alloc(&ws->d_status_out, 1);
@@ -1234,7 +1316,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     }
     if (!ws->clean) {
         // first batch, or a previous batch did not run to its finalize kernel
-        HIPCHK(hipMemsetAsync(ws->d_pool_cursor, 0, (size_t)2 * CURSOR_STRIDE * sizeof(unsigned long long), s));
+        HIPCHK(hipMemsetAsync(ws->d_pool_cursor, 0, (size_t)3 * CURSOR_STRIDE * sizeof(unsigned long long), s));
         HIPCHK(hipMemsetAsync(ws->d_list_counts, 0, N_SMALL_SLOTS * sizeof(uint32_t), s));
         HIPCHK(hipMemsetAsync(ws->d_counter_replicas, 0, sizeof(unsigned long long) * CTR_REPLICAS * CTR_N, s));
         HIPCHK(hipMemsetAsync(ws->d_valid, 0, (size_t)(ws->pos_cap / 64 + 2) * sizeof(unsigned long long), s));
@@ -1391,6 +1473,12 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         pp2.group_queue = ws->d_list_counts + SLOT_GROUP_QUEUE_POS;
         pp2.ovf_list = list_ptr(LIST_SO); pp2.ovf_count = ws->d_list_counts + LIST_SO;
         launch_group_positions(pp2, (int)grp_blocks, s);
+        CountParams pg2 = pg;   // the G tier's queries: their hit lists are final, the counting arena is free again
+        pg2.fin_out = nullptr;
+        pg2.pos_base = ws->d_pos_base;
+        pg2.pos_bits = ws->d_pos_bits;
+        pg2.g_cursor = ws->d_pool_cursor + 2 * CURSOR_STRIDE;
+        hipLaunchKernelGGL(positions_global_kernel, dim3(g_grid), dim3(64 * G_WAVES), 0, s, pg2);
     }
     if (!fused_finalize)
         hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->d_counter_replicas, ws->d_counters, ws->d_list_counts,
@@ -1424,7 +1512,7 @@ int kaamer_merge_device(kaamer_workspace *ws, const uint64_t *d_ent_off, const u
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(ws->device));
     if (!ws->clean) {
-        HIPCHK(hipMemsetAsync(ws->d_pool_cursor, 0, (size_t)2 * CURSOR_STRIDE * sizeof(unsigned long long), s));
+        HIPCHK(hipMemsetAsync(ws->d_pool_cursor, 0, (size_t)3 * CURSOR_STRIDE * sizeof(unsigned long long), s));
         HIPCHK(hipMemsetAsync(ws->d_list_counts, 0, N_SMALL_SLOTS * sizeof(uint32_t), s));
         HIPCHK(hipMemsetAsync(ws->d_counter_replicas, 0, sizeof(unsigned long long) * CTR_REPLICAS * CTR_N, s));
         HIPCHK(hipMemsetAsync(ws->d_valid, 0, (size_t)(ws->pos_cap / 64 + 2) * sizeof(unsigned long long), s));
@@ -1560,8 +1648,6 @@ int kaamer_workspace_finish(kaamer_workspace *ws, void *stream, kaamer_counters 
     if (status & (ST_QUERY_CAP | ST_AA_CAP))
         return kaamer_fail(KAAMER_E_CAPACITY, "more ORFs than the workspace holds: raise workspace max_queries (now %u)", ws->q_cap);
     if (status & ST_POS_CAP) return kaamer_fail(KAAMER_E_CAPACITY, "position bitmaps exceed the workspace: raise max_pos_words (now %llu)", (unsigned long long)ws->bits_cap);
-    if (status & ST_POS_UNSUPPORTED)
-        return kaamer_fail(KAAMER_E_CAPACITY, "position bitmaps are not available for queries with more distinct hits than an on-chip table holds (G tier)");
     if (status & ST_G_ARENA_FULL)
         return kaamer_fail(KAAMER_E_CAPACITY, "global counting arena exhausted: raise workspace g_tier_slots (now %llu)", (unsigned long long)ws->g_slots);
     if (status) return kaamer_fail(KAAMER_E_CAPACITY, "device status 0x%x", status);

@@ -272,3 +272,26 @@ def test_position_bitmaps(small, oracle):
             assert int(got[p].sum()) == int(km[i])
             n_bits += int(km[i])
     assert n_bits == res.counters["n_post"]
+
+
+def test_position_bitmaps_g_tier(klib, oracle, gpu_device):
+    """PositionHits of queries counted in the HBM tier (more distinct hits than an LDS table holds)"""
+    from kaamer_amd import api
+    rng = np.random.default_rng(14)
+    alpha = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
+    core = bytes(alpha[rng.integers(0, 20, 70)])
+    db = [bytes(alpha[rng.integers(0, 20, 6)]) + core[(i % 9):] + bytes(alpha[rng.integers(0, 20, 6)]) for i in range(3000)]
+    ids = rng.permutation(20000)[:3000].astype(np.uint32)
+    ix = api.Index.from_image(api.Image.from_proteins(db, ids=ids), gpu_device)
+    oix = oracle.Index.from_proteins(db, ids=ids)
+    seqs = [core, bytes(alpha[rng.integers(0, 20, 130)]) + core + bytes(alpha[rng.integers(0, 20, 70)]), db[11], core[:25]]
+    res = ix.search(seqs, want_positions=True)
+    assert res.counters["n_overflow"] >= 2
+    for qi, s in enumerate(seqs):
+        pid, km, pos = oix.search(s, want_positions=True)
+        got = res.positions(qi)
+        assert sorted(got) == sorted(pid.tolist())
+        if qi < 2:
+            assert len(pid) == 3000
+        for i, p in enumerate(pid.tolist()):
+            assert got[p].tolist() == pos[i].tolist(), (qi, p)
