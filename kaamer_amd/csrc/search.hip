@@ -615,8 +615,14 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
         }
         GlobalTable gt;
         gt.keys = p.g_keys + off; gt.cnt = p.g_cnt + off; gt.minpos = p.g_min + off; gt.nd = &s_nd; gt.log2cap = log2cap;
-        for (unsigned long long i = tid; i < cap; i += 64 * WAVES) { gt.keys[i] = KH_EMPTY_PID; gt.cnt[i] = 0; gt.minpos[i] = 0xFFFFFFFFu; }
-        __threadfence();
+        // The table is only ever touched with device-scope atomics (initialisation included), which
+        // are performed past the L2: no agent-scope fence -- a full L2 write-back on this part -- is
+        // needed between the phases, a workgroup barrier (which drains vmcnt) is enough.
+        for (unsigned long long i = tid; i < cap; i += 64 * WAVES) {
+            __hip_atomic_store(&gt.keys[i], KH_EMPTY_PID, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&gt.cnt[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&gt.minpos[i], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         __syncthreads();
         // pass 2: count
         pc.clear();
@@ -625,7 +631,6 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
                                                                    pc, s_pref[wv]);
             if (!ok) s_fail = 1;
         }
-        __threadfence();
         __syncthreads();
         // lookups, postings and queries were already counted by the group kernel
         const uint32_t total = s_nd;
@@ -731,17 +736,15 @@ __global__ __launch_bounds__(64 * G_WAVES) void positions_global_kernel(CountPar
         const unsigned long long off = s_off;
         if (off == ~0ull || cnt == 0 || size <= 0) { __syncthreads(); continue; }
         uint32_t *keys = p.g_keys + off, *idx = p.g_cnt + off;
-        for (unsigned long long i = tid; i < cap; i += 64 * WAVES) keys[i] = KH_EMPTY_PID;
-        __threadfence();
+        for (unsigned long long i = tid; i < cap; i += 64 * WAVES) __hip_atomic_store(&keys[i], KH_EMPTY_PID, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         const uint32_t mask = (uint32_t)cap - 1u;
         for (uint32_t i = tid; i < cnt; i += 64 * WAVES) {
             const uint32_t pid = p.hit_pid[hoff + i];
             uint32_t h = (pid * 0x9E3779B1u) >> (32 - log2cap);
             while (atomicCAS(&keys[h], KH_EMPTY_PID, pid) != KH_EMPTY_PID) h = (h + 1u) & mask;  // ids are distinct, load <= 0.5
-            idx[h] = i;
+            __hip_atomic_store(&idx[h], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        __threadfence();
         __syncthreads();
         BitsTable bt;
         bt.keys = keys; bt.idx = idx; bt.nd = &s_nd; bt.log2cap = log2cap;
