@@ -84,8 +84,8 @@ def cpu_baseline(oix, queries, seconds=12.0, threads=None, kind="protein"):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--db-proteins", type=int, default=560000)
     ap.add_argument("--workload", choices=["protein", "reads"], default="protein",
                     help="protein = BASELINE configs[1] (default); reads = configs[2]: 150-nt reads, 6-frame path")

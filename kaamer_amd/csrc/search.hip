@@ -221,7 +221,13 @@ __global__ __launch_bounds__(64 * P_WAVES) void probe_kernel(ProbeParams p)
             rbk[j] = __shfl(bucket, src, 64);
             rkey[j] = __shfl(key, src, 64);
             ld[j] = make_uint4(KH_EMPTY_KEY, 0, KH_EMPTY_KEY, 0);
-            if (rkey[j] != KH_EMPTY_KEY) ld[j] = p.table[(uint64_t)rbk[j] * 4 + (lane & 3u)];
+            // nontemporal: a bucket is read once per batch; keeping it out of the way of the lines the
+            // counting kernel re-reads (vals, list heads) is worth 8 us per batch downstream
+            if (rkey[j] != KH_EMPTY_KEY) {
+                typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+                const v4u t = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p.table) + (uint64_t)rbk[j] * 4 + (lane & 3u));
+                ld[j] = make_uint4(t.x, t.y, t.z, t.w);
+            }
         }
         uint32_t okey = KH_EMPTY_KEY, oval = 0, obucket = 0;
         bool oempty = true;
