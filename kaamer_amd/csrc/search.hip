@@ -155,6 +155,7 @@ struct ProbeParams {
     const unsigned long long *d_n_pos;  // device scalar: number of residue positions
     uint32_t *vals;
     unsigned long long *counters;
+    uint32_t nontemporal;  // bucket loads bypass the caches (small batch against a large table)
 };
 
 #define P_WAVES 4
@@ -221,11 +222,14 @@ __global__ __launch_bounds__(64 * P_WAVES) void probe_kernel(ProbeParams p)
             rbk[j] = __shfl(bucket, src, 64);
             rkey[j] = __shfl(key, src, 64);
             ld[j] = make_uint4(KH_EMPTY_KEY, 0, KH_EMPTY_KEY, 0);
-            // nontemporal: a bucket is read once per batch; keeping it out of the way of the lines the
-            // counting kernel re-reads (vals, list heads) is worth 8 us per batch downstream
+            // nontemporal when the batch is small against the table (a bucket is then read once per
+            // batch): keeping it out of the way of the lines the counting kernel re-reads (vals, list
+            // heads) is worth 8 us per 10 000-query batch downstream.  A 1 M-read batch touches every
+            // bucket several times and wants them cached (+9 % probe time when nontemporal).
             if (rkey[j] != KH_EMPTY_KEY) {
                 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-                const v4u t = __builtin_nontemporal_load(reinterpret_cast<const v4u *>(p.table) + (uint64_t)rbk[j] * 4 + (lane & 3u));
+                const v4u *src = reinterpret_cast<const v4u *>(p.table) + (uint64_t)rbk[j] * 4 + (lane & 3u);
+                const v4u t = p.nontemporal ? __builtin_nontemporal_load(src) : *src;
                 ld[j] = make_uint4(t.x, t.y, t.z, t.w);
             }
         }
@@ -301,6 +305,8 @@ struct CountParams {
     uint32_t list_cap;
     uint32_t *queue_head;  // workgroups of the last kernel that have finished (zeroed by finalize)
     uint32_t *group_queue; // tickets of the group kernel (zeroed by finalize)
+    const uint2 *sched;    // ticket -> (group, first query), longest groups first
+    const uint32_t *d_n_sched;
     // results, written straight into their final place: hits of query q are
     // [hit_off[q], hit_off[q] + q_cnt[q]) of the three SoA arrays, with hit_off[q] = E[q], the
     // first slot of the query's counting table in the batch's table layout (a table never holds
@@ -1010,6 +1016,8 @@ struct kaamer_workspace {
     int32_t *d_starts_alt;
     uint32_t max_seqs;
     unsigned long long *d_chain;        // layout_kernel: one word per tile, tagged with the batch epoch
+    uint2 *d_sched;                     // schedule_kernel: ticket -> (group, first query)
+    uint32_t *d_n_sched;
     // post-steps (kaamer_topn_device), allocated on first use
     uint32_t topn_k;
     uint32_t *d_top_cnt, *d_top_pid, *d_top_km, *d_top_fp;
@@ -1125,7 +1133,7 @@ void kaamer_workspace_free(kaamer_workspace *ws)
                      ws->d_tmp_meta, ws->d_orf_aa, ws->d_starts_alt, ws->d_q_cnt, ws->d_csr_off, ws->d_c_pid, ws->d_c_km, ws->d_c_fp,
                      ws->d_pool_cursor, ws->d_lists, ws->d_list_counts, ws->d_status_out, ws->d_qinfo, ws->d_slots,
                      ws->d_slot_off, ws->d_group_first, ws->d_n_groups, ws->d_pos_words, ws->d_pos_base, ws->d_pos_off, ws->d_pos_bits, ws->d_g_keys,
-                     ws->d_g_cnt, ws->d_g_min, ws->d_counter_replicas, ws->d_counters, ws->d_bsum, ws->d_chain, ws->d_top_cnt, ws->d_top_pid, ws->d_top_km, ws->d_top_fp, ws->d_top_trim, ws->d_top_start, ws->d_top_size, ws->d_hit_off,
+                     ws->d_g_cnt, ws->d_g_min, ws->d_counter_replicas, ws->d_counters, ws->d_bsum, ws->d_chain, ws->d_sched, ws->d_n_sched, ws->d_top_cnt, ws->d_top_pid, ws->d_top_km, ws->d_top_fp, ws->d_top_trim, ws->d_top_start, ws->d_top_size, ws->d_hit_off,
                      ws->d_hit_pid, ws->d_hit_km, ws->d_hit_fp };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (ws->ev) {
@@ -1219,6 +1227,8 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     if (!rc) rc = dev_alloc(&ws->d_slots, ws->q_cap);
     if (!rc) rc = dev_alloc(&ws->d_slot_off, (size_t)ws->q_cap + 1);
     if (!rc) rc = dev_alloc(&ws->d_group_first, ws->groups_cap);
+    if (!rc) rc = dev_alloc(&ws->d_sched, ws->groups_cap);
+    if (!rc) rc = dev_alloc(&ws->d_n_sched, 1);
     if (!rc) rc = dev_alloc(&ws->d_n_groups, 1);
 
     ws->want_positions = opts->want_positions != 0;
@@ -1266,6 +1276,8 @@ static void launch_layout(kaamer_workspace *ws, uint32_t nq_bound, uint32_t *sta
     const uint32_t tiles = (uint32_t)(((uint64_t)nq_bound + 1 + LAY_TILE - 1) / LAY_TILE);
     hipLaunchKernelGGL(layout_kernel, dim3(tiles), dim3(LAY_THREADS), 0, s, ws->d_slots, ws->d_nq, ws->d_slot_off, ws->d_group_first,
                        ws->d_n_groups, ws->groups_cap, ws->d_chain, ws->lay_epoch, status);
+    hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(1024), 0, s, ws->d_group_first, ws->d_slot_off, ws->d_n_groups, ws->d_nq,
+                       ws->d_sched, ws->d_n_sched);
 }
 
 // optional last step of a search / merge: CSR in query order from the sharded hit arrays
@@ -1397,6 +1409,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     pp.d_n_pos = ws->d_n_pos;
     pp.vals = ws->d_vals;
     pp.counters = ws->d_counter_replicas;
+    pp.nontemporal = pos_bound < ix->hdr.n_buckets ? 1u : 0u;
     uint64_t p_blocks = (pos_bound / 64 + 1 + P_WAVES - 1) / P_WAVES;
     if (p_blocks > (uint64_t)ws->p_grid) p_blocks = ws->p_grid;
     if (p_blocks < 1) p_blocks = 1;
@@ -1411,6 +1424,8 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     p.qinfo = ws->d_qinfo;
     p.slot_off = ws->d_slot_off;
     p.group_first = ws->d_group_first;
+    p.sched = ws->d_sched;
+    p.d_n_sched = ws->d_n_sched;
     p.d_n_groups = ws->d_n_groups;
     p.d_nq = ws->d_nq;
     p.list_cap = ws->q_cap;
@@ -1538,6 +1553,8 @@ int kaamer_merge_device(kaamer_workspace *ws, const uint64_t *d_ent_off, const u
     p.qinfo = ws->d_qinfo;
     p.slot_off = ws->d_slot_off;
     p.group_first = ws->d_group_first;
+    p.sched = ws->d_sched;
+    p.d_n_sched = ws->d_n_sched;
     p.d_n_groups = ws->d_n_groups;
     p.d_nq = ws->d_nq;
     p.last_group_pass = 1u;
