@@ -1017,6 +1017,7 @@ struct kaamer_workspace {
     uint32_t max_seqs;
     unsigned long long *d_chain;        // layout_kernel: one word per tile, tagged with the batch epoch
     uint2 *d_sched;                     // schedule_kernel: ticket -> (group, first query)
+    uint64_t *d_group_start;            // layout_kernel: slot at which the group's first table starts
     uint32_t *d_n_sched;
     // post-steps (kaamer_topn_device), allocated on first use
     uint32_t topn_k;
@@ -1133,7 +1134,7 @@ void kaamer_workspace_free(kaamer_workspace *ws)
                      ws->d_tmp_meta, ws->d_orf_aa, ws->d_starts_alt, ws->d_q_cnt, ws->d_csr_off, ws->d_c_pid, ws->d_c_km, ws->d_c_fp,
                      ws->d_pool_cursor, ws->d_lists, ws->d_list_counts, ws->d_status_out, ws->d_qinfo, ws->d_slots,
                      ws->d_slot_off, ws->d_group_first, ws->d_n_groups, ws->d_pos_words, ws->d_pos_base, ws->d_pos_off, ws->d_pos_bits, ws->d_g_keys,
-                     ws->d_g_cnt, ws->d_g_min, ws->d_counter_replicas, ws->d_counters, ws->d_bsum, ws->d_chain, ws->d_sched, ws->d_n_sched, ws->d_top_cnt, ws->d_top_pid, ws->d_top_km, ws->d_top_fp, ws->d_top_trim, ws->d_top_start, ws->d_top_size, ws->d_hit_off,
+                     ws->d_g_cnt, ws->d_g_min, ws->d_counter_replicas, ws->d_counters, ws->d_bsum, ws->d_chain, ws->d_sched, ws->d_n_sched, ws->d_group_start, ws->d_top_cnt, ws->d_top_pid, ws->d_top_km, ws->d_top_fp, ws->d_top_trim, ws->d_top_start, ws->d_top_size, ws->d_hit_off,
                      ws->d_hit_pid, ws->d_hit_km, ws->d_hit_fp };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (ws->ev) {
@@ -1228,6 +1229,7 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     if (!rc) rc = dev_alloc(&ws->d_slot_off, (size_t)ws->q_cap + 1);
     if (!rc) rc = dev_alloc(&ws->d_group_first, ws->groups_cap);
     if (!rc) rc = dev_alloc(&ws->d_sched, ws->groups_cap);
+    if (!rc) rc = dev_alloc(&ws->d_group_start, ws->groups_cap);
     if (!rc) rc = dev_alloc(&ws->d_n_sched, 1);
     if (!rc) rc = dev_alloc(&ws->d_n_groups, 1);
 
@@ -1275,9 +1277,9 @@ static void launch_layout(kaamer_workspace *ws, uint32_t nq_bound, uint32_t *sta
     if (ws->lay_epoch == 0) ws->lay_epoch = 1;
     const uint32_t tiles = (uint32_t)(((uint64_t)nq_bound + 1 + LAY_TILE - 1) / LAY_TILE);
     hipLaunchKernelGGL(layout_kernel, dim3(tiles), dim3(LAY_THREADS), 0, s, ws->d_slots, ws->d_nq, ws->d_slot_off, ws->d_group_first,
-                       ws->d_n_groups, ws->groups_cap, ws->d_chain, ws->lay_epoch, status);
-    hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(1024), 0, s, ws->d_group_first, ws->d_slot_off, ws->d_n_groups, ws->d_nq,
-                       ws->d_sched, ws->d_n_sched);
+                       ws->d_group_start, ws->d_n_groups, ws->groups_cap, ws->d_chain, ws->lay_epoch, status);
+    hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(1024), 0, s, ws->d_group_first, ws->d_group_start, ws->d_slot_off, ws->d_n_groups,
+                       ws->d_nq, ws->d_sched, ws->d_n_sched);
 }
 
 // optional last step of a search / merge: CSR in query order from the sharded hit arrays
