@@ -2,24 +2,30 @@
 //
 // What runs on the device, per batch (all on the caller's stream, no host sync):
 //
-//   translate_kernel x2 + orf_order_kernel   nucleotide input only (translate.hip.inc):
-//                         GetORFs (dna.go:65-181) -> ORF batch
-//   prep_protein_kernel / prep_orf_kernel    Query.SizeInKmer etc. (search.go:290-293;
-//                         search_protein.go:70-76), the bitmap of positions that start no
-//                         k-mer, an LDS table capacity per query
-//   scan + group_build_kernel                packs consecutive queries into groups (side
-//                         stream, beside the probe kernel)
+//   translate_short_kernel / translate_kernel (COUNT + WRITE) + orf_order_kernel
+//                         nucleotide input only (translate.hip.inc): GetORFs (dna.go:65-181)
+//                         -> ORF batch; a lane per read for reads, a wave per (sequence, frame)
+//                         for longer sequences
+//   prep_layout_schedule_kernel   protein input (count_group.hip.inc): Query.SizeInKmer etc.
+//                         (search.go:290-293; search_protein.go:70-76), the bitmap of positions
+//                         that start no k-mer, an LDS table capacity per query, the table
+//                         layout E (exclusive scan), the first query of every query group and
+//                         the order the groups are handed out in (longest first) -- one launch
+//   prep_orf_kernel + layout_kernel + schedule_kernel    the same for an ORF batch
 //   probe_kernel          the dominant kernel: flat over residue positions; sliding 7-mer
 //                         encode (k_store.go:91-117, search_protein.go:94-98) and bucket
 //                         probe (replaces KmerStore.Get, search.go:421) -> vals[pos]
 //   count_group_kernel    (count_group.hip.inc) postings expansion + Counter increments
 //                         (search.go:427-436, 442-452) in LDS hash tables, one 8-wave
-//                         workgroup per query group; ballot/popcount compaction
+//                         workgroup per query group; a wave per query packs its table into
+//                         the query's hit list at E[q]
 //   count_global_kernel   G tier: queries whose distinct hits exceed their LDS table count
-//                         into an exactly sized table in HBM
-//   scan + gather_hits_kernel                hit lists -> CSR in query order
+//                         into an exactly sized table in HBM; its last workgroup finalizes
+//                         the batch (counters, status, per-batch state left zeroed)
+//   [scan + gather_hits_kernel]   opts.compact: hit lists -> CSR in query order
 //   [positions pass]      PositionHits bitmaps when asked for
-//   finalize_kernel       counters, status, and all per-batch state left zeroed
+//   [topn_kernel]         kaamer_topn_device: sortMapByValue order, SetBestStartCodon,
+//                         FilterResults (topn.hip.inc)
 //
 // This is integer hashing/indexing: no MFMA.  The probe is bound by the memory system's
 // random-request rate (~51e9 requests/s on MI355X whatever the size up to 128 B,
@@ -91,7 +97,7 @@ static_assert(sizeof(kaamer_counters) == CTR_N * 8, "counter layout");
 enum { LIST_S = 0, LIST_L, LIST_SO, LIST_G, N_LISTS };
 // small per-batch device state after the list counters (all zeroed by the finalize step)
 enum { SLOT_QUEUE_HEAD = N_LISTS, SLOT_STATUS = N_LISTS + 1, SLOT_GROUP_QUEUE = N_LISTS + 2, SLOT_GROUP_QUEUE_POS = N_LISTS + 3,
-       SLOT_N_LONG = N_LISTS + 4, N_SMALL_SLOTS = N_LISTS + 5 };
+       SLOT_N_LONG = N_LISTS + 4, SLOT_TILES_DONE = N_LISTS + 5, N_SMALL_SLOTS = N_LISTS + 6 };
 // one entry: everything a tier needs to start on a query, in one 16-byte load
 struct alignas(16) WorkItem {
     uint32_t q;
@@ -540,6 +546,20 @@ __device__ __forceinline__ bool count_windows(const CountParams &p, const uint32
     return __all(ok);
 }
 
+// sets bits [b, e) of the not-a-k-mer-start bitmap
+__device__ __forceinline__ void mark_invalid_range(unsigned long long *invalid, uint64_t b, uint64_t e)
+{
+    // sets bits [b, e)
+    while (b < e) {
+        const uint64_t w = b >> 6;
+        const uint64_t hi = ((w + 1) << 6) < e ? ((w + 1) << 6) : e;
+        const unsigned nb = (unsigned)(hi - b);
+        const unsigned long long m = (nb == 64 ? ~0ull : ((1ull << nb) - 1ull)) << (b & 63);
+        atomicOr(&invalid[w], m);
+        b = hi;
+    }
+}
+
 #include "count_group.hip.inc"
 
 // ---- G tier: counting table in HBM, sized from the query's exact postings count -------------------
@@ -771,67 +791,6 @@ __global__ __launch_bounds__(64 * G_WAVES) void positions_global_kernel(CountPar
     }
 }
 
-// ------------------------------------------------------------------------------------
-// prep: protein records -> query meta (search.go:286-296; search_protein.go:70-76),
-// the not-a-k-mer-start bitmap (all zero on entry) and the tier work lists.
-// ------------------------------------------------------------------------------------
-__device__ __forceinline__ void mark_invalid_range(unsigned long long *invalid, uint64_t b, uint64_t e)
-{
-    // sets bits [b, e)
-    while (b < e) {
-        const uint64_t w = b >> 6;
-        const uint64_t hi = ((w + 1) << 6) < e ? ((w + 1) << 6) : e;
-        const unsigned nb = (unsigned)(hi - b);
-        const unsigned long long m = (nb == 64 ? ~0ull : ((1ull << nb) - 1ull)) << (b & 63);
-        atomicOr(&invalid[w], m);
-        b = hi;
-    }
-}
-
-__global__ void prep_protein_kernel(const uint8_t *seqs, const uint64_t *offsets, uint32_t n_seqs,
-                                    kaamer_query_meta *q, uint32_t *d_nq, unsigned long long *d_n_pos,
-                                    unsigned long long *invalid, QInfo *qinfo, uint32_t *slots, uint64_t *hit_off,
-                                    uint32_t *q_cnt)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) {
-        const uint64_t n_pos = offsets[n_seqs];
-        *d_nq = n_seqs;
-        *d_n_pos = n_pos;
-        mark_invalid_range(invalid, n_pos, (n_pos + 63) & ~63ull);  // bits past the end, in the last word P reads
-    }
-    if (i >= n_seqs) return;
-    const uint64_t b = offsets[i], e = offsets[i + 1];
-    const int64_t len = (int64_t)(e - b);
-    int32_t size = (int32_t)(len - KAAMER_KMER_SIZE + 1);       // search.go:290
-    if (len > 0 && seqs[e - 1] == '*') size--;                  // search.go:291-293
-    kaamer_query_meta m;
-    m.src_seq = i;
-    m.size_in_kmer = size;
-    m.start_position = 1;                                       // search.go:225,303
-    m.end_position = (int32_t)len;                              // search.go:294
-    m.plus_strand = 1;
-    m.aa_len = (uint32_t)len;
-    m.aa_off = b;
-    m.sa_off = 0;
-    m.sa_len = 0;
-    q[i] = m;
-    q_cnt[i] = 0;
-    hit_off[i] = 0;
-    QInfo qi;
-    qi.size = size;
-    qi.aa_off = b;
-    if (size >= 7) {                                            // search_protein.go:74-76
-        qi.slots = table_slots_for(size);
-        mark_invalid_range(invalid, b + (uint64_t)size, e);      // positions >= SizeInKmer start no k-mer
-    } else {
-        qi.slots = 0;
-        mark_invalid_range(invalid, b, e);                       // the whole query is dropped
-    }
-    qinfo[i] = qi;
-    slots[i] = qi.slots;
-}
-
 #include "translate.hip.inc"
 #include "topn.hip.inc"
 
@@ -1018,6 +977,7 @@ struct kaamer_workspace {
     unsigned long long *d_chain;        // layout_kernel: one word per tile, tagged with the batch epoch
     uint2 *d_sched;                     // schedule_kernel: ticket -> (group, first query)
     uint64_t *d_group_start;            // layout_kernel: slot at which the group's first table starts
+    unsigned long long *d_lay_total;    // total table slots of the batch
     uint32_t *d_n_sched;
     // post-steps (kaamer_topn_device), allocated on first use
     uint32_t topn_k;
@@ -1134,7 +1094,7 @@ void kaamer_workspace_free(kaamer_workspace *ws)
                      ws->d_tmp_meta, ws->d_orf_aa, ws->d_starts_alt, ws->d_q_cnt, ws->d_csr_off, ws->d_c_pid, ws->d_c_km, ws->d_c_fp,
                      ws->d_pool_cursor, ws->d_lists, ws->d_list_counts, ws->d_status_out, ws->d_qinfo, ws->d_slots,
                      ws->d_slot_off, ws->d_group_first, ws->d_n_groups, ws->d_pos_words, ws->d_pos_base, ws->d_pos_off, ws->d_pos_bits, ws->d_g_keys,
-                     ws->d_g_cnt, ws->d_g_min, ws->d_counter_replicas, ws->d_counters, ws->d_bsum, ws->d_chain, ws->d_sched, ws->d_n_sched, ws->d_group_start, ws->d_top_cnt, ws->d_top_pid, ws->d_top_km, ws->d_top_fp, ws->d_top_trim, ws->d_top_start, ws->d_top_size, ws->d_hit_off,
+                     ws->d_g_cnt, ws->d_g_min, ws->d_counter_replicas, ws->d_counters, ws->d_bsum, ws->d_chain, ws->d_sched, ws->d_n_sched, ws->d_group_start, ws->d_lay_total, ws->d_top_cnt, ws->d_top_pid, ws->d_top_km, ws->d_top_fp, ws->d_top_trim, ws->d_top_start, ws->d_top_size, ws->d_hit_off,
                      ws->d_hit_pid, ws->d_hit_km, ws->d_hit_fp };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (ws->ev) {
@@ -1230,6 +1190,7 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     if (!rc) rc = dev_alloc(&ws->d_group_first, ws->groups_cap);
     if (!rc) rc = dev_alloc(&ws->d_sched, ws->groups_cap);
     if (!rc) rc = dev_alloc(&ws->d_group_start, ws->groups_cap);
+    if (!rc) rc = dev_alloc(&ws->d_lay_total, 1);
     if (!rc) rc = dev_alloc(&ws->d_n_sched, 1);
     if (!rc) rc = dev_alloc(&ws->d_n_groups, 1);
 
@@ -1247,8 +1208,8 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     if (!rc) rc = dev_alloc(&ws->d_counter_replicas, (size_t)CTR_REPLICAS * CTR_N);
     if (!rc) rc = dev_alloc(&ws->d_counters, 1);
     if (!rc) rc = dev_alloc(&ws->d_bsum, ws->n_scan_blocks);
-    if (!rc) rc = dev_alloc(&ws->d_chain, (size_t)ws->q_cap / LAY_TILE + 2);
-    if (!rc && hipMemset(ws->d_chain, 0, ((size_t)ws->q_cap / LAY_TILE + 2) * sizeof(unsigned long long)) != hipSuccess) rc = kaamer_fail(KAAMER_E_HIP, "memset");
+    if (!rc) rc = dev_alloc(&ws->d_chain, (size_t)ws->q_cap / PL_TILE + 2);
+    if (!rc && hipMemset(ws->d_chain, 0, ((size_t)ws->q_cap / PL_TILE + 2) * sizeof(unsigned long long)) != hipSuccess) rc = kaamer_fail(KAAMER_E_HIP, "memset");
     if (!rc) rc = dev_alloc(&ws->d_hit_off, (size_t)ws->q_cap + 1);
     ws->compact = opts->compact != 0;
     if (!rc) rc = dev_alloc(&ws->d_hit_pid, ws->sparse_cap);
@@ -1353,9 +1314,22 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     uint64_t pos_bound = seq_bytes;     // host-side bound of the residue positions (grid sizing only)
     uint32_t nq_bound = n_seqs;         // host-side bound of the number of queries
     if (!nucl) {
-        hipLaunchKernelGGL(prep_protein_kernel, dim3((n_seqs + pb - 1) / pb > 0 ? (n_seqs + pb - 1) / pb : 1), dim3(pb), 0, s,
-                           d_seqs, d_offsets, n_seqs, ws->d_q, ws->d_nq, ws->d_n_pos, ws->d_valid, ws->d_qinfo, ws->d_slots,
-                           ws->d_hit_off, ws->d_q_cnt);
+        // prep + table layout + group schedule: one launch (count_group.hip.inc)
+        PrepLayoutParams pl;
+        memset(&pl, 0, sizeof pl);
+        pl.seqs = d_seqs; pl.offsets = d_offsets; pl.n_seqs = n_seqs;
+        pl.q = ws->d_q; pl.d_nq = ws->d_nq; pl.d_n_pos = ws->d_n_pos; pl.invalid = ws->d_valid; pl.qinfo = ws->d_qinfo;
+        pl.hit_off = ws->d_hit_off; pl.q_cnt = ws->d_q_cnt;
+        pl.E = ws->d_slot_off; pl.group_first = ws->d_group_first; pl.group_start = ws->d_group_start;
+        pl.d_n_groups = ws->d_n_groups; pl.groups_cap = ws->groups_cap; pl.chain = ws->d_chain;
+        ws->lay_epoch = (ws->lay_epoch + 1u) & 0xFFFFFFu;
+        if (ws->lay_epoch == 0) ws->lay_epoch = 1;
+        pl.epoch = ws->lay_epoch;
+        pl.status = status; pl.sched = ws->d_sched; pl.d_n_sched = ws->d_n_sched;
+        pl.tiles_done = ws->d_list_counts + SLOT_TILES_DONE;
+        pl.d_total = ws->d_lay_total;
+        const uint32_t tiles = (uint32_t)(((uint64_t)n_seqs + 1 + PL_TILE - 1) / PL_TILE);
+        hipLaunchKernelGGL(prep_layout_schedule_kernel, dim3(tiles), dim3(LAY_THREADS), 0, s, pl);
     } else {
         // 6-frame translation: count, scan, write, order (translate.hip.inc)
         const size_t n6 = (size_t)n_seqs * 6, cap6 = (size_t)ws->max_seqs * 6;
@@ -1397,8 +1371,8 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         nq_bound = ws->q_cap;
     }
 
-    // ---- query groups: table layout and the first query of each group
-    launch_layout(ws, nq_bound, status, s);
+    // ---- query groups: table layout, first query of each group, schedule (protein: done with the prep)
+    if (nucl) launch_layout(ws, nq_bound, status, s);
 
     // ---- kernel P: flat probe
     ProbeParams pp;
