@@ -18,7 +18,7 @@ DST = os.path.join(ROOT, "profiles")
 
 
 def one(pattern):
-    fs = sorted(glob.glob(os.path.join(SRC, pattern)))
+    fs = sorted(glob.glob(os.path.join(SRC, pattern)), key=os.path.getmtime)  # gpurun merges runs: take the newest
     if not fs:
         raise SystemExit("missing " + pattern)
     return fs[-1]
