@@ -105,6 +105,8 @@ def main():
                          "FilterResults: kaamer_topn_device with the reference's defaults)")
     ap.add_argument("--host-api", type=int, default=0,
                     help="1: also time the host-buffer calls once (PCIe-inclusive, informational, never `value`)")
+    ap.add_argument("--pipelined-probe", type=int, default=1,
+                    help="after the timed region also measure the same batches with three in flight (informational field)")
     ap.add_argument("--inflight", type=int, default=1,
                     help="batches in flight: step i runs on workspace/stream i %% inflight, so the probe kernel of one batch "
                          "(memory-request bound) overlaps the counting kernel of the previous one (LDS/latency bound)")
@@ -217,6 +219,29 @@ def main():
     tm = ws.kernel_ms_sum()
     n_calls = max(tm["calls"], 1)
 
+    # informational, after the timed region and never `value`: the same batches with three in flight on
+    # three streams/workspaces (the next batch's probe kernel overlaps this batch's counting kernel)
+    pipelined = None
+    if not sharded_mode and world == 1 and args.inflight == 1 and args.pipelined_probe:
+        pw = [ws] + [api.Workspace(ix, len(qbuf), args.queries, seq_type=abi.READS if reads else abi.PROTEIN,
+                                   max_hits=(64 << 20) if reads else 0, compact=bool(args.compact)) for _ in range(2)]
+        pstr_keep = [torch.cuda.Stream() for _ in range(2)]
+        pstr = [stream] + [x.cuda_stream for x in pstr_keep]
+        ws.set_timing(0)
+        n_p = max(30, min(args.steps, 300)) if not reads else 9
+        for i in range(6):
+            pw[i % 3].search_device(d_buf.data_ptr(), d_off.data_ptr(), args.queries, len(qbuf), stream=pstr[i % 3])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_p):
+            pw[i % 3].search_device(d_buf.data_ptr(), d_off.data_ptr(), args.queries, len(qbuf), stream=pstr[i % 3])
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        for w_, s_ in zip(pw, pstr):
+            w_.finish(s_)
+        pipelined = {"batches_in_flight": 3, "steps": n_p, "ms_per_step": dt / n_p * 1e3,
+                     "lookups_per_s": float(counters["n_lookup"]) * n_p / dt}
+
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
     lk = torch.tensor([float(counters["n_lookup"]), float(args.queries) / (world if sharded_mode else 1)],
                       dtype=torch.float64, device="cuda")
@@ -283,6 +308,8 @@ def main():
         "counters_per_step_rank0": c,
         "roofline": roofline,
     }
+    if pipelined:
+        out["pipelined_informational"] = pipelined
 
     if rank == 0:
         want_cpu = not args.no_cpu_baseline and world == 1 and not sharded_mode
