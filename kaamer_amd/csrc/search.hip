@@ -970,6 +970,11 @@ struct kaamer_workspace {
     uint32_t *d_cnt3;                   // [3][6*max_seqs] ORF / aa / starts counts per (sequence, frame)
     uint64_t *d_off3;                   // [3][6*max_seqs+1] their exclusive scans
     uint32_t *d_n6;                     // device scalar 6*n_seqs
+    // long sequences (> TS_MAX nt) are translated piece-wise: list, pieces per frame, per-piece counts and their scans
+    uint32_t max_long;
+    uint64_t max_piece_items;
+    uint32_t *d_long_seq, *d_long_np, *d_pcnt3, *d_n_piece_items;
+    uint64_t *d_piece_base, *d_poff3;
     kaamer_query_meta *d_tmp_meta;
     uint8_t *d_orf_aa;
     int32_t *d_starts_alt;
@@ -1090,7 +1095,7 @@ void kaamer_workspace_free(kaamer_workspace *ws)
 {
     if (!ws) return;
     (void)hipSetDevice(ws->device);
-    void *bufs[] = { ws->d_q, ws->d_nq, ws->d_n_pos, ws->d_valid, ws->d_vals, ws->d_cnt3, ws->d_off3, ws->d_n6,
+    void *bufs[] = { ws->d_q, ws->d_nq, ws->d_n_pos, ws->d_valid, ws->d_vals, ws->d_cnt3, ws->d_off3, ws->d_n6, ws->d_long_seq, ws->d_long_np, ws->d_pcnt3, ws->d_n_piece_items, ws->d_piece_base, ws->d_poff3,
                      ws->d_tmp_meta, ws->d_orf_aa, ws->d_starts_alt, ws->d_q_cnt, ws->d_csr_off, ws->d_c_pid, ws->d_c_km, ws->d_c_fp,
                      ws->d_pool_cursor, ws->d_lists, ws->d_list_counts, ws->d_status_out, ws->d_qinfo, ws->d_slots,
                      ws->d_slot_off, ws->d_group_first, ws->d_n_groups, ws->d_pos_words, ws->d_pos_base, ws->d_pos_off, ws->d_pos_bits, ws->d_g_keys,
@@ -1163,6 +1168,12 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     {
         uint64_t n = ws->q_cap;
         if (ws->nucleotide && (uint64_t)ws->max_seqs * 6 > n) n = (uint64_t)ws->max_seqs * 6;
+        if (ws->nucleotide) {
+            const uint64_t ml = opts->max_seq_bytes / (TS_MAX + 1) + 1;
+            ws->max_long = (uint32_t)(ml < ws->max_seqs ? ml : ws->max_seqs);
+            ws->max_piece_items = 6ull * (opts->max_seq_bytes / 3 / TP_PIECE + ws->max_long + 1);
+            if (ws->max_piece_items > n) n = ws->max_piece_items;
+        }
         ws->n_scan_blocks = (uint32_t)((n + 1 + SCAN_TILE - 1) / SCAN_TILE);
     }
     rc = dev_alloc(&ws->d_q, ws->q_cap);
@@ -1175,6 +1186,12 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
         rc = dev_alloc(&ws->d_cnt3, 3 * n6);
         if (!rc) rc = dev_alloc(&ws->d_off3, 3 * (n6 + 1));
         if (!rc) rc = dev_alloc(&ws->d_n6, 1);
+        if (!rc) rc = dev_alloc(&ws->d_long_seq, (size_t)ws->max_long + 1);
+        if (!rc) rc = dev_alloc(&ws->d_long_np, (size_t)ws->max_long + 1);
+        if (!rc) rc = dev_alloc(&ws->d_piece_base, (size_t)ws->max_long + 2);
+        if (!rc) rc = dev_alloc(&ws->d_pcnt3, 3 * (size_t)ws->max_piece_items);
+        if (!rc) rc = dev_alloc(&ws->d_poff3, 3 * ((size_t)ws->max_piece_items + 1));
+        if (!rc) rc = dev_alloc(&ws->d_n_piece_items, 1);
         if (!rc) rc = dev_alloc(&ws->d_tmp_meta, ws->q_cap);
         if (!rc) rc = dev_alloc(&ws->d_orf_aa, (size_t)ws->aa_cap + 64);
         if (!rc) rc = dev_alloc(&ws->d_starts_alt, (size_t)ws->sa_cap + 64);
@@ -1340,14 +1357,38 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         tp.off_orf = ws->d_off3; tp.off_aa = ws->d_off3 + (cap6 + 1); tp.off_sa = ws->d_off3 + 2 * (cap6 + 1);
         tp.tmp_meta = ws->d_tmp_meta; tp.orf_aa = ws->d_orf_aa; tp.starts_alt = ws->d_starts_alt;
         tp.q_cap = ws->q_cap; tp.aa_cap = ws->aa_cap; tp.sa_cap = ws->sa_cap; tp.status = status;
-        int tgrid = ws->n_cu * 8;  // 256-thread blocks, one (sequence, frame) item per wave at a time
-        if ((uint64_t)tgrid * 4 > n6) tgrid = n6 > 0 ? (int)((n6 + 3) / 4) : 1;
+        int tgrid = ws->n_cu * 8;  // 256-thread blocks, one (sequence, frame, piece) item per wave at a time
         tp.d_n6 = ws->d_n6;
         int sgrid = ws->n_cu * 5;  // lane-per-read kernel: 2-wave blocks, ~31 KB of LDS each
         if ((uint64_t)sgrid * TS_WAVES * 64 > (uint64_t)n_seqs) sgrid = n_seqs > 0 ? (int)(((uint64_t)n_seqs + TS_WAVES * 64 - 1) / (TS_WAVES * 64)) : 1;
         tp.n_long = ws->d_list_counts + SLOT_N_LONG;
+        const size_t mpi = (size_t)ws->max_piece_items;
+        tp.long_seq = ws->d_long_seq; tp.long_np = ws->d_long_np; tp.piece_base = ws->d_piece_base;
+        tp.pcnt_orf = ws->d_pcnt3; tp.pcnt_aa = ws->d_pcnt3 + mpi; tp.pcnt_sa = ws->d_pcnt3 + 2 * mpi;
+        tp.poff_orf = ws->d_poff3; tp.poff_aa = ws->d_poff3 + (mpi + 1); tp.poff_sa = ws->d_poff3 + 2 * (mpi + 1);
+        tp.d_n_piece_items = ws->d_n_piece_items;
+        auto scan_u32 = [&](const uint32_t *cnt, const uint32_t *d_count, uint64_t bound, uint64_t *off) {
+            if (bound <= 8 * (uint64_t)SCAN_TILE) {
+                hipLaunchKernelGGL(scan_single_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, cnt, d_count, off);
+            } else {
+                const uint32_t nsb = (uint32_t)((bound + 1 + SCAN_TILE - 1) / SCAN_TILE);
+                hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nsb), dim3(SCAN_BLOCK), 0, s, cnt, d_count, ws->d_bsum);
+                hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, ws->d_bsum, nsb);
+                hipLaunchKernelGGL(scan_apply_kernel, dim3(nsb), dim3(SCAN_BLOCK), 0, s, cnt, d_count, ws->d_bsum, off);
+            }
+        };
+        // reads: a lane each; longer sequences: listed, cut in pieces, a wave per piece
+        const uint64_t long_bound = (uint64_t)ws->max_long < n_seqs ? ws->max_long : n_seqs;
+        const uint64_t seq_long_max = seq_bytes / (TS_MAX + 1) + 1;
+        const uint64_t n_long_bound = long_bound < seq_long_max ? long_bound : seq_long_max;
+        const uint64_t piece_bound = 6ull * (seq_bytes / 3 / TP_PIECE + n_long_bound + 1);
+        if ((uint64_t)tgrid * 4 > piece_bound) tgrid = (int)((piece_bound + 3) / 4);
+        if (tgrid < 1) tgrid = 1;
         hipLaunchKernelGGL(translate_short_kernel<false>, dim3(sgrid), dim3(64 * TS_WAVES), 0, s, tp);
+        scan_u32(ws->d_long_np, tp.n_long, n_long_bound, ws->d_piece_base);
         hipLaunchKernelGGL(translate_kernel<false>, dim3(tgrid), dim3(256), 0, s, tp);
+        for (int a = 0; a < 3; a++) scan_u32(ws->d_pcnt3 + a * mpi, ws->d_n_piece_items, piece_bound, ws->d_poff3 + a * (mpi + 1));
+        hipLaunchKernelGGL(long_totals_kernel, dim3((unsigned)((n_long_bound * 6 + 255) / 256)), dim3(256), 0, s, tp);
         const uint32_t nsb6 = (uint32_t)((n6 + 1 + SCAN_TILE - 1) / SCAN_TILE);
         for (int a = 0; a < 3; a++) {
             const uint32_t *cnt = ws->d_cnt3 + a * cap6;

@@ -163,3 +163,31 @@ def test_reads_position_bitmaps(small, oracle):
                 assert got[p].tolist() == pos[i].tolist()
                 n += 1
     assert n > 100
+
+
+def test_contig_piece_boundaries(small, oracle):
+    """long sequences are translated in pieces of 4096 codons per frame: ORFs that start in one piece
+    and close in a later one, stops on the last / first codon of a piece, a stop-free frame longer
+    than two pieces, unknown bases across a boundary, lengths around the piece size"""
+    db, ix, oix = small
+    rng = np.random.default_rng(77)
+
+    def rnd(n):
+        return bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n)])
+
+    P = 4096
+    orf = lambda n_codons: b"ATG" + b"GCA" * (n_codons - 2) + b"TAA"   # n_codons incl. start and stop
+    contigs = [
+        orf(P) + orf(30) + rnd(3000),                       # stop on the last codon of piece 0
+        orf(P + 1) + orf(30) + rnd(3000),                   # stop on the first codon of piece 1
+        orf(P - 1) + orf(25) + rnd(100),                    # next ORF starts on the last codon of piece 0
+        b"GCA" * (2 * P + 500),                             # stop-free: one ORF over three pieces, open at both ends
+        rnd(5000) + orf(9000) + rnd(5000),                  # an ORF crossing two boundaries inside random sequence
+        b"AC" + orf(P) + rnd(64),                           # frame 3 carries the construct
+        rnd(3 * P - 40) + b"N" * 90 + rnd(2000),            # unknown bases across the boundary
+        rnd(3 * P), rnd(3 * P + 1), rnd(3 * P + 2), rnd(3 * P + 3), rnd(6 * P + 5),
+        rnd(193), rnd(192), rnd(200000),
+    ]
+    res = ix.search(contigs, seq_type=abi.NUCLEOTIDE)
+    n = _check_reads(res, contigs, oracle, oix)
+    assert n > 1000
