@@ -53,7 +53,8 @@ def build_send(hit_off, hit_cnt, pid, km, fp, world):
     q_splits = [n_owned(nq, world, d) for d in range(world)]
     bounds = np.cumsum([0] + q_splits)
     csum = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(cnt_p, 0)])
-    e_splits = [int(csum[bounds[d + 1]] - csum[bounds[d]]) for d in range(world)]
+    edges = csum[torch.as_tensor(bounds, dtype=torch.int64, device=dev)].tolist()  # one host sync for all destinations
+    e_splits = [int(edges[d + 1] - edges[d]) for d in range(world)]
     return cnt_p, ents.contiguous(), q_splits, e_splits
 
 
