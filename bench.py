@@ -105,7 +105,7 @@ def main():
                          "FilterResults: kaamer_topn_device with the reference's defaults)")
     ap.add_argument("--host-api", type=int, default=0,
                     help="1: also time the host-buffer calls once (PCIe-inclusive, informational, never `value`)")
-    ap.add_argument("--pipelined-probe", type=int, default=1,
+    ap.add_argument("--pipelined-probe", type=int, default=0,
                     help="after the timed region also measure the same batches with three in flight (informational field)")
     ap.add_argument("--inflight", type=int, default=1,
                     help="batches in flight: step i runs on workspace/stream i %% inflight, so the probe kernel of one batch "
