@@ -1733,12 +1733,68 @@ void kaamer_workspace_set_timing(kaamer_workspace *ws, uint32_t every)
 // ------------------------------------------------------------------------------------
 // host-buffer form
 // ------------------------------------------------------------------------------------
+// The hit arrays of kaamer_search_batch (tens of MB) land in pinned host memory: a D2H copy into fresh
+// pageable memory runs at 2-3 GB/s here.  Pinned buffers are kept in a small process-wide cache.
+extern "C++" {
+namespace {
+struct PinnedCache {
+    std::mutex mu;
+    std::vector<std::pair<void *, size_t>> free_list;
+};
+PinnedCache g_pinned;
+
+void *pinned_get(size_t bytes, size_t *cap)
+{
+    {
+        std::lock_guard<std::mutex> lock(g_pinned.mu);
+        size_t best = (size_t)-1;
+        for (size_t i = 0; i < g_pinned.free_list.size(); i++)
+            if (g_pinned.free_list[i].second >= bytes && (best == (size_t)-1 || g_pinned.free_list[i].second < g_pinned.free_list[best].second)) best = i;
+        if (best != (size_t)-1) {
+            void *p = g_pinned.free_list[best].first;
+            *cap = g_pinned.free_list[best].second;
+            g_pinned.free_list.erase(g_pinned.free_list.begin() + (long)best);
+            return p;
+        }
+    }
+    void *p = nullptr;
+    const size_t want = bytes + bytes / 4 + 4096;
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) return nullptr;
+    *cap = want;
+    return p;
+}
+
+void pinned_put(void *p, size_t cap)
+{
+    std::lock_guard<std::mutex> lock(g_pinned.mu);
+    if (g_pinned.free_list.size() < 12) g_pinned.free_list.emplace_back(p, cap);
+    else (void)hipHostFree(p);
+}
+
+template <class T> struct PinnedArr {
+    T *p = nullptr;
+    size_t cap = 0;
+    PinnedArr() = default;
+    PinnedArr(const PinnedArr &) = delete;
+    PinnedArr &operator=(const PinnedArr &) = delete;
+    ~PinnedArr() { if (p) pinned_put(p, cap); }
+    bool resize(size_t n)
+    {
+        if (p) { pinned_put(p, cap); p = nullptr; }
+        p = (T *)pinned_get((n ? n : 1) * sizeof(T), &cap);
+        return p != nullptr;
+    }
+    T *data() { return p; }
+};
+}  // namespace
+}  // extern "C++"
+
 struct batch_out_owner {
     kaamer_batch_out pub;
     std::vector<kaamer_query_meta> q;
     std::vector<uint64_t> hit_off;
     std::vector<uint32_t> hit_cnt;
-    std::vector<uint32_t> pid, km, fp;
+    PinnedArr<uint32_t> pid, km, fp;
     std::vector<uint8_t> orf_aa;
     std::vector<int32_t> starts_alt;
     std::vector<uint64_t> pos_off, pos_bits;
@@ -1827,8 +1883,8 @@ static int search_batch_once(kaamer_index *ix, const kaamer_batch_in *in, uint64
     if (e == hipSuccess) e = hipMemcpy(bo->hit_off.data(), dr.d_hit_off, ((size_t)nq + 1) * 8, hipMemcpyDeviceToHost);
     if (e == hipSuccess) {
         n_hits = bo->hit_off[nq];
-        bo->pid.resize(n_hits); bo->km.resize(n_hits); bo->fp.resize(n_hits);
-        if (n_hits) {
+        if (!bo->pid.resize(n_hits) || !bo->km.resize(n_hits) || !bo->fp.resize(n_hits)) e = hipErrorOutOfMemory;
+        if (e == hipSuccess && n_hits) {
             e = hipMemcpy(bo->pid.data(), dr.d_hit_pid, n_hits * 4, hipMemcpyDeviceToHost);
             if (e == hipSuccess) e = hipMemcpy(bo->km.data(), dr.d_hit_kmatch, n_hits * 4, hipMemcpyDeviceToHost);
             if (e == hipSuccess) e = hipMemcpy(bo->fp.data(), dr.d_hit_first_pos, n_hits * 4, hipMemcpyDeviceToHost);
