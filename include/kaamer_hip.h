@@ -268,23 +268,27 @@ typedef struct {
 
 int kaamer_topn_device(kaamer_workspace *ws, const kaamer_topn_opts *opts, void *stream,
                        kaamer_topn_result *out);
-/* Host-buffer call that returns what the reference's drivers report per query
- * (search_protein.go:105-112, search_fastq.go:118-126): the hits that survive
- * FilterResults, in sortMapByValue order, after SetBestStartCodon for nucleotide /
- * reads input (best_start_codon is set from in->seq_type).  Only
- * n_queries x max_results entries cross PCIe.  A query with top_cnt == 0 is not
- * reported by the reference.  q[i] carries Location.StartPosition, SizeInKmer and the
- * Sequence window (aa_off, aa_len) as they are after SetBestStartCodon. */
+/* Host-buffer call that returns what the reference's drivers report
+ * (search_protein.go:105-112, search_fastq.go:118-126): the queries FilterResults left
+ * with at least one hit, their hits in sortMapByValue order, after SetBestStartCodon
+ * for nucleotide / reads input (best_start_codon is set from in->seq_type).  The
+ * packing is done on the device: only the reported queries, their hits (CSR) and their
+ * ORF residues cross PCIe.  q[i] carries Location.StartPosition, SizeInKmer and the
+ * Sequence window (aa_off, aa_len) as they are after SetBestStartCodon; aa_off indexes
+ * orf_aa below (nucleotide / reads) or the caller's own input (protein). */
 typedef struct {
-    uint32_t n_queries;
+    uint32_t n_queries;             /* queries (proteins / ORFs) searched      */
+    uint32_t n_reported;            /* those with a hit left after the filter  */
     uint32_t max_results;
-    const kaamer_query_meta *q;
+    const uint32_t *rep_query;      /* [n_reported] index among the n_queries, */
+                                    /* ascending (ORFs: the reference's order) */
+    const kaamer_query_meta *q;     /* [n_reported]                            */
     const int32_t *trim;            /* residues removed from the ORF head      */
-    const uint32_t *top_cnt;
-    const uint32_t *top_pid;        /* [i * max_results + r], r < top_cnt[i]   */
+    const uint64_t *top_off;        /* [n_reported + 1] CSR into the arrays    */
+    const uint32_t *top_pid;
     const uint32_t *top_kmatch;
     const uint32_t *top_first_pos;  /* relative to the untrimmed ORF           */
-    const uint8_t *orf_aa;          /* nucleotide / reads: ORF amino acids     */
+    const uint8_t *orf_aa;          /* reported ORFs' residues, concatenated   */
     kaamer_counters counters;
 } kaamer_batch_top;
 

@@ -83,8 +83,9 @@ class TopnOpts(C.Structure):
 
 
 class BatchTop(C.Structure):
-    _fields_ = [("n_queries", C.c_uint32), ("max_results", C.c_uint32), ("q", C.POINTER(QueryMeta)),
-                ("trim", C.POINTER(C.c_int32)), ("top_cnt", C.POINTER(C.c_uint32)), ("top_pid", C.POINTER(C.c_uint32)),
+    _fields_ = [("n_queries", C.c_uint32), ("n_reported", C.c_uint32), ("max_results", C.c_uint32),
+                ("rep_query", C.POINTER(C.c_uint32)), ("q", C.POINTER(QueryMeta)), ("trim", C.POINTER(C.c_int32)),
+                ("top_off", C.POINTER(C.c_uint64)), ("top_pid", C.POINTER(C.c_uint32)),
                 ("top_kmatch", C.POINTER(C.c_uint32)), ("top_first_pos", C.POINTER(C.c_uint32)),
                 ("orf_aa", C.POINTER(C.c_uint8)), ("counters", Counters)]
 

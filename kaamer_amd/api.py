@@ -95,24 +95,41 @@ META_DTYPE = np.dtype([("src_seq", "<u4"), ("size_in_kmer", "<i4"), ("start_posi
 
 
 class TopResult:
-    """Host view of one kaamer_batch_top (copied out, the C object is freed)."""
+    """Host view of one kaamer_batch_top (copied out, the C object is freed): the reported queries
+    (`rep_query`, `meta`, `trim`, CSR `top_off` + `top_pid` / `top_kmatch` / `top_first_pos`, `orf_aa`),
+    plus dense per-query views for convenience (`top_cnt[n_queries]`, `dense()`)."""
 
     def __init__(self, out):
         o = out.contents
-        n, k = o.n_queries, o.max_results
-        self.n_queries, self.max_results = n, k
-        meta = np.ctypeslib.as_array(C.cast(o.q, C.POINTER(C.c_uint8)), shape=(n * C.sizeof(abi.QueryMeta),)).copy() \
-            if n else np.zeros(0, np.uint8)
-        self.meta = meta.view(META_DTYPE)
+        n, r, k = o.n_queries, o.n_reported, o.max_results
+        self.n_queries, self.n_reported, self.max_results = n, r, k
         z = np.zeros(0, np.uint32)
-        self.trim = np.ctypeslib.as_array(o.trim, shape=(n,)).copy() if n else np.zeros(0, np.int32)
-        self.top_cnt = np.ctypeslib.as_array(o.top_cnt, shape=(n,)).copy() if n else z
-        self.top_pid = np.ctypeslib.as_array(o.top_pid, shape=(n * k,)).copy().reshape(n, k) if n else z.reshape(0, k)
-        self.top_kmatch = np.ctypeslib.as_array(o.top_kmatch, shape=(n * k,)).copy().reshape(n, k) if n else z.reshape(0, k)
-        self.top_first_pos = np.ctypeslib.as_array(o.top_first_pos, shape=(n * k,)).copy().reshape(n, k) if n else z.reshape(0, k)
-        aa_len = int((self.meta["aa_off"] + self.meta["aa_len"]).max()) if n and bool(o.orf_aa) else 0
+        self.rep_query = np.ctypeslib.as_array(o.rep_query, shape=(r,)).copy() if r else z
+        meta = np.ctypeslib.as_array(C.cast(o.q, C.POINTER(C.c_uint8)), shape=(r * C.sizeof(abi.QueryMeta),)).copy() \
+            if r else np.zeros(0, np.uint8)
+        self.meta = meta.view(META_DTYPE)
+        self.trim = np.ctypeslib.as_array(o.trim, shape=(r,)).copy() if r else np.zeros(0, np.int32)
+        self.top_off = np.ctypeslib.as_array(o.top_off, shape=(r + 1,)).copy()
+        ne = int(self.top_off[r])
+        self.top_pid = np.ctypeslib.as_array(o.top_pid, shape=(ne,)).copy() if ne else z
+        self.top_kmatch = np.ctypeslib.as_array(o.top_kmatch, shape=(ne,)).copy() if ne else z
+        self.top_first_pos = np.ctypeslib.as_array(o.top_first_pos, shape=(ne,)).copy() if ne else z
+        aa_len = int((self.meta["aa_off"] + self.meta["aa_len"]).max()) if r and bool(o.orf_aa) else 0
         self.orf_aa = np.ctypeslib.as_array(o.orf_aa, shape=(aa_len,)).copy() if aa_len else np.zeros(0, np.uint8)
         self.counters = o.counters.as_dict()
+        self.top_cnt = np.zeros(n, np.uint32)
+        if r:
+            self.top_cnt[self.rep_query] = np.diff(self.top_off.astype(np.int64)).astype(np.uint32)
+
+    def dense(self):
+        """(top_pid, top_kmatch) as [n_queries, max_results] arrays, zero beyond top_cnt"""
+        pid = np.zeros((self.n_queries, self.max_results), np.uint32)
+        km = np.zeros((self.n_queries, self.max_results), np.uint32)
+        for i in range(self.n_reported):
+            a, b = int(self.top_off[i]), int(self.top_off[i + 1])
+            pid[self.rep_query[i], :b - a] = self.top_pid[a:b]
+            km[self.rep_query[i], :b - a] = self.top_kmatch[a:b]
+        return pid, km
 
 
 class BatchResult:

@@ -989,6 +989,13 @@ struct kaamer_workspace {
     uint32_t *d_top_cnt, *d_top_pid, *d_top_km, *d_top_fp;
     int32_t *d_top_trim, *d_top_start, *d_top_size;
     bool last_was_merge;
+    // reported-only packing of the top-N results (kaamer_search_batch_top), allocated on first use
+    uint32_t rep_k;
+    uint32_t *d_rep_flag, *d_rep_aalen, *d_rep_query, *d_rep_pid, *d_rep_km, *d_rep_fp;
+    int32_t *d_rep_trim;
+    uint64_t *d_rep_rank, *d_rep_eoff, *d_rep_aoff, *d_rep_off;
+    kaamer_query_meta *d_rep_q;
+    uint8_t *d_rep_aa;
     uint32_t lay_epoch;
     uint32_t *d_list_counts;            // [N_LISTS] + queue head + status (zeroed by finalize)
     uint32_t *d_status_out;             // status of the last finished batch
@@ -1099,7 +1106,7 @@ void kaamer_workspace_free(kaamer_workspace *ws)
                      ws->d_tmp_meta, ws->d_orf_aa, ws->d_starts_alt, ws->d_q_cnt, ws->d_csr_off, ws->d_c_pid, ws->d_c_km, ws->d_c_fp,
                      ws->d_pool_cursor, ws->d_lists, ws->d_list_counts, ws->d_status_out, ws->d_qinfo, ws->d_slots,
                      ws->d_slot_off, ws->d_group_first, ws->d_n_groups, ws->d_pos_words, ws->d_pos_base, ws->d_pos_off, ws->d_pos_bits, ws->d_g_keys,
-                     ws->d_g_cnt, ws->d_g_min, ws->d_counter_replicas, ws->d_counters, ws->d_bsum, ws->d_chain, ws->d_sched, ws->d_n_sched, ws->d_group_start, ws->d_lay_total, ws->d_top_cnt, ws->d_top_pid, ws->d_top_km, ws->d_top_fp, ws->d_top_trim, ws->d_top_start, ws->d_top_size, ws->d_hit_off,
+                     ws->d_g_cnt, ws->d_g_min, ws->d_counter_replicas, ws->d_counters, ws->d_bsum, ws->d_chain, ws->d_sched, ws->d_n_sched, ws->d_group_start, ws->d_lay_total, ws->d_top_cnt, ws->d_top_pid, ws->d_top_km, ws->d_top_fp, ws->d_top_trim, ws->d_top_start, ws->d_top_size, ws->d_rep_flag, ws->d_rep_aalen, ws->d_rep_query, ws->d_rep_pid, ws->d_rep_km, ws->d_rep_fp, ws->d_rep_trim, ws->d_rep_rank, ws->d_rep_eoff, ws->d_rep_aoff, ws->d_rep_off, ws->d_rep_q, ws->d_rep_aa, ws->d_hit_off,
                      ws->d_hit_pid, ws->d_hit_km, ws->d_hit_fp };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (ws->ev) {
@@ -1952,11 +1959,72 @@ int kaamer_search_batch(kaamer_index *ix, const kaamer_batch_in *in, kaamer_batc
 // ---- host-buffer form that returns what a caller reports: the filtered top hits only ----------
 struct batch_top_owner {
     kaamer_batch_top pub;
+    std::vector<uint32_t> rep_query;
     std::vector<kaamer_query_meta> q;
     std::vector<int32_t> trim;
-    std::vector<uint32_t> cnt, pid, km, fp;
+    std::vector<uint64_t> off;
+    std::vector<uint32_t> pid, km, fp;
     std::vector<uint8_t> orf_aa;
 };
+
+static void scan_u32_on(kaamer_workspace *ws, const uint32_t *cnt, const uint32_t *d_count, uint64_t bound, uint64_t *off, hipStream_t s)
+{
+    if (bound <= 8 * (uint64_t)SCAN_TILE) {
+        hipLaunchKernelGGL(scan_single_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, cnt, d_count, off);
+    } else {
+        const uint32_t nsb = (uint32_t)((bound + 1 + SCAN_TILE - 1) / SCAN_TILE);
+        hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nsb), dim3(SCAN_BLOCK), 0, s, cnt, d_count, ws->d_bsum);
+        hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, ws->d_bsum, nsb);
+        hipLaunchKernelGGL(scan_apply_kernel, dim3(nsb), dim3(SCAN_BLOCK), 0, s, cnt, d_count, ws->d_bsum, off);
+    }
+}
+
+// packs the reported queries of the last kaamer_topn_device call (topn.hip.inc)
+static int topn_pack_reported(kaamer_workspace *ws, const kaamer_topn_result *tr, bool nucl, hipStream_t s, RepParams *rp)
+{
+    if (ws->rep_k < tr->max_results) {
+        uint32_t **bufs[] = { &ws->d_rep_pid, &ws->d_rep_km, &ws->d_rep_fp };
+        for (uint32_t **b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
+        const size_t n = (size_t)ws->q_cap * tr->max_results;
+        int rc = dev_alloc(&ws->d_rep_pid, n);
+        if (!rc) rc = dev_alloc(&ws->d_rep_km, n);
+        if (!rc) rc = dev_alloc(&ws->d_rep_fp, n);
+        if (!rc && !ws->d_rep_flag) {
+            rc = dev_alloc(&ws->d_rep_flag, ws->q_cap);
+            if (!rc) rc = dev_alloc(&ws->d_rep_aalen, ws->q_cap);
+            if (!rc) rc = dev_alloc(&ws->d_rep_query, ws->q_cap);
+            if (!rc) rc = dev_alloc(&ws->d_rep_trim, ws->q_cap);
+            if (!rc) rc = dev_alloc(&ws->d_rep_rank, (size_t)ws->q_cap + 1);
+            if (!rc) rc = dev_alloc(&ws->d_rep_eoff, (size_t)ws->q_cap + 1);
+            if (!rc) rc = dev_alloc(&ws->d_rep_aoff, (size_t)ws->q_cap + 1);
+            if (!rc) rc = dev_alloc(&ws->d_rep_off, (size_t)ws->q_cap + 1);
+            if (!rc) rc = dev_alloc(&ws->d_rep_q, ws->q_cap);
+            if (!rc && ws->nucleotide) rc = dev_alloc(&ws->d_rep_aa, (size_t)ws->aa_cap + 64);
+        }
+        if (rc) { ws->rep_k = 0; return rc; }
+        ws->rep_k = tr->max_results;
+    }
+    RepParams p;
+    memset(&p, 0, sizeof p);
+    p.d_nq = ws->d_nq; p.q = ws->d_q; p.top_cnt = tr->d_top_cnt;
+    p.trim = tr->d_trim; p.start_pos = tr->d_start_position; p.size_out = tr->d_size_in_kmer;
+    p.K = tr->max_results;
+    p.top_pid = tr->d_top_pid; p.top_km = tr->d_top_kmatch; p.top_fp = tr->d_top_first_pos;
+    p.orf_aa = nucl ? ws->d_orf_aa : nullptr;
+    p.flag = ws->d_rep_flag; p.aalen = ws->d_rep_aalen;
+    p.rank = ws->d_rep_rank; p.eoff = ws->d_rep_eoff; p.aoff = ws->d_rep_aoff;
+    p.rep_query = ws->d_rep_query; p.rep_q = ws->d_rep_q; p.rep_trim = ws->d_rep_trim; p.rep_off = ws->d_rep_off;
+    p.rep_pid = ws->d_rep_pid; p.rep_km = ws->d_rep_km; p.rep_fp = ws->d_rep_fp; p.rep_aa = ws->d_rep_aa;
+    const uint64_t bound = ws->q_cap;
+    hipLaunchKernelGGL(rep_flags_kernel, dim3(ws->n_cu * 4), dim3(256), 0, s, p);
+    scan_u32_on(ws, ws->d_rep_flag, ws->d_nq, bound, ws->d_rep_rank, s);
+    scan_u32_on(ws, tr->d_top_cnt, ws->d_nq, bound, ws->d_rep_eoff, s);
+    scan_u32_on(ws, ws->d_rep_aalen, ws->d_nq, bound, ws->d_rep_aoff, s);
+    hipLaunchKernelGGL(rep_gather_kernel, dim3(ws->n_cu * 8), dim3(256), 0, s, p);
+    HIPCHK(hipGetLastError());
+    *rp = p;
+    return KAAMER_OK;
+}
 
 static int search_batch_top_once(kaamer_index *ix, const kaamer_batch_in *in, const kaamer_topn_opts *top, uint64_t max_hits,
                                  uint64_t g_slots, uint32_t max_queries, kaamer_batch_top **out)
@@ -1983,8 +2051,10 @@ static int search_batch_top_once(kaamer_index *ix, const kaamer_batch_in *in, co
     kaamer_device_result dr;
     kaamer_topn_result tr;
     kaamer_topn_opts t = *top;
+    RepParams rp;
     kaamer_counters c;
     uint32_t nq = 0;
+    uint64_t n_rep = 0, n_ent = 0, n_aa = 0;
     hipError_t e;
     t.best_start_codon = nucl ? 1u : 0u;  // search_fastq.go:121, search_nucleotide.go:118; not in search_protein.go
     t.d_size_in_kmer = nullptr;
@@ -1993,48 +2063,42 @@ static int search_batch_top_once(kaamer_index *ix, const kaamer_batch_in *in, co
     if (e != hipSuccess) { rc = kaamer_fail(KAAMER_E_HIP, "H2D: %s", hipGetErrorString(e)); goto done; }
     rc = kaamer_search_device(ix, ws, d_seqs, d_off, in->n_seqs, seq_bytes, in->seq_type, s, &dr);
     if (!rc) rc = kaamer_topn_device(ws, &t, s, &tr);
+    if (!rc) rc = topn_pack_reported(ws, &tr, nucl, s, &rp);
     if (!rc) rc = kaamer_workspace_finish(ws, s, &c);
     if (rc) goto done;
     bo = new (std::nothrow) batch_top_owner();
     if (!bo) { rc = kaamer_fail(KAAMER_E_NOMEM, "batch_top"); goto done; }
     e = hipMemcpy(&nq, dr.d_n_queries, 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(&n_rep, rp.rank + nq, 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(&n_ent, rp.eoff + nq, 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(&n_aa, rp.aoff + nq, 8, hipMemcpyDeviceToHost);
     if (e == hipSuccess) {
-        const size_t nk = (size_t)nq * t.max_results;
-        bo->q.resize((size_t)nq + 1); bo->trim.resize((size_t)nq + 1); bo->cnt.resize((size_t)nq + 1);
-        bo->pid.resize(nk + 1); bo->km.resize(nk + 1); bo->fp.resize(nk + 1);
-        if (nq) {
-            std::vector<int32_t> sp(nq), sz(nq);
-            e = hipMemcpy(bo->q.data(), dr.d_q, (size_t)nq * sizeof(kaamer_query_meta), hipMemcpyDeviceToHost);
-            if (e == hipSuccess) e = hipMemcpy(bo->trim.data(), tr.d_trim, (size_t)nq * 4, hipMemcpyDeviceToHost);
-            if (e == hipSuccess) e = hipMemcpy(sp.data(), tr.d_start_position, (size_t)nq * 4, hipMemcpyDeviceToHost);
-            if (e == hipSuccess) e = hipMemcpy(sz.data(), tr.d_size_in_kmer, (size_t)nq * 4, hipMemcpyDeviceToHost);
-            if (e == hipSuccess) e = hipMemcpy(bo->cnt.data(), tr.d_top_cnt, (size_t)nq * 4, hipMemcpyDeviceToHost);
-            if (e == hipSuccess) e = hipMemcpy(bo->pid.data(), tr.d_top_pid, nk * 4, hipMemcpyDeviceToHost);
-            if (e == hipSuccess) e = hipMemcpy(bo->km.data(), tr.d_top_kmatch, nk * 4, hipMemcpyDeviceToHost);
-            if (e == hipSuccess) e = hipMemcpy(bo->fp.data(), tr.d_top_first_pos, nk * 4, hipMemcpyDeviceToHost);
-            // the query as the reference reports it after SetBestStartCodon (dna.go:252-267)
-            for (uint32_t i = 0; e == hipSuccess && i < nq; i++) {
-                kaamer_query_meta &m = bo->q[i];
-                m.start_position = sp[i];
-                m.size_in_kmer = sz[i];
-                m.aa_off += (uint64_t)bo->trim[i];
-                m.aa_len -= (uint32_t)bo->trim[i];
-            }
+        bo->rep_query.resize(n_rep + 1); bo->q.resize(n_rep + 1); bo->trim.resize(n_rep + 1); bo->off.resize(n_rep + 1);
+        bo->pid.resize(n_ent + 1); bo->km.resize(n_ent + 1); bo->fp.resize(n_ent + 1);
+        bo->orf_aa.resize(n_aa + 1);
+        bo->off[n_rep] = 0;
+        if (n_rep) {
+            e = hipMemcpy(bo->rep_query.data(), rp.rep_query, n_rep * 4, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(bo->q.data(), rp.rep_q, n_rep * sizeof(kaamer_query_meta), hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(bo->trim.data(), rp.rep_trim, n_rep * 4, hipMemcpyDeviceToHost);
         }
-    }
-    if (e == hipSuccess && nucl) {
-        unsigned long long n_aa = 0;
-        e = hipMemcpy(&n_aa, ws->d_n_pos, sizeof n_aa, hipMemcpyDeviceToHost);
-        if (e == hipSuccess) bo->orf_aa.resize(n_aa + 1);
-        if (e == hipSuccess && n_aa) e = hipMemcpy(bo->orf_aa.data(), dr.d_orf_aa, n_aa, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(bo->off.data(), rp.rep_off, (n_rep + 1) * 8, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && n_ent) {
+            e = hipMemcpy(bo->pid.data(), rp.rep_pid, n_ent * 4, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(bo->km.data(), rp.rep_km, n_ent * 4, hipMemcpyDeviceToHost);
+            if (e == hipSuccess) e = hipMemcpy(bo->fp.data(), rp.rep_fp, n_ent * 4, hipMemcpyDeviceToHost);
+        }
+        if (e == hipSuccess && n_aa) e = hipMemcpy(bo->orf_aa.data(), rp.rep_aa, n_aa, hipMemcpyDeviceToHost);
     }
     if (e != hipSuccess) { rc = kaamer_fail(KAAMER_E_HIP, "D2H: %s", hipGetErrorString(e)); goto done; }
     memset(&bo->pub, 0, sizeof bo->pub);
     bo->pub.n_queries = nq;
+    bo->pub.n_reported = (uint32_t)n_rep;
     bo->pub.max_results = t.max_results;
+    bo->pub.rep_query = bo->rep_query.data();
     bo->pub.q = bo->q.data();
     bo->pub.trim = bo->trim.data();
-    bo->pub.top_cnt = bo->cnt.data();
+    bo->pub.top_off = bo->off.data();
     bo->pub.top_pid = bo->pid.data();
     bo->pub.top_kmatch = bo->km.data();
     bo->pub.top_first_pos = bo->fp.data();

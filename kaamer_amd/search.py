@@ -50,15 +50,14 @@ def ProteinSearch(index, fasta_text, options=None):
         top = index.search_top([q["seq"] for q in queries], seq_type=abi.PROTEIN, min_k_ratio=o.MinKRatio,
                                min_k_match=o.MinKMatch, max_results=o.MaxResults)
         out = []
-        for i, q in enumerate(queries):
-            keep = int(top.top_cnt[i])
-            if q["size"] < 7 or keep == 0:  # search_protein.go:74-76, :108
-                continue
+        for r in range(top.n_reported):   # search_protein.go:74-76, :108: the others are not reported
+            q = queries[int(top.rep_query[r])]
+            a, b = int(top.top_off[r]), int(top.top_off[r + 1])
             out.append({"Query": {"Sequence": q["seq"], "Name": q["name"], "SizeInKmer": q["size"], "Type": PROTEIN_QUERY,
                                   "Location": {"StartPosition": 1, "EndPosition": len(q["seq"]), "PlusStrand": True,
                                                "StartsAlternative": []}, "Contig": ""},
                         "SearchResults": {"Hits": [{"Key": int(p), "Kmatch": int(k)}
-                                                   for p, k in zip(top.top_pid[i, :keep], top.top_kmatch[i, :keep])]}})
+                                                   for p, k in zip(top.top_pid[a:b], top.top_kmatch[a:b])]}})
         return out
     res = index.search([q["seq"] for q in queries], seq_type=abi.PROTEIN, want_positions=o.ExtractPositions)
     out = []
@@ -86,10 +85,8 @@ def _orf_results(index, reads, names, o, seq_type):
         top = index.search_top(reads, seq_type=seq_type, min_k_ratio=o.MinKRatio, min_k_match=o.MinKMatch,
                                max_results=o.MaxResults)
         out = []
-        for i in range(top.n_queries):
-            keep = int(top.top_cnt[i])
-            if keep == 0:
-                continue
+        for i in range(top.n_reported):
+            a, b = int(top.top_off[i]), int(top.top_off[i + 1])
             m = top.meta[i]
             aa = bytes(top.orf_aa[int(m["aa_off"]):int(m["aa_off"]) + int(m["aa_len"])])  # already trimmed
             out.append({"Query": {"Sequence": aa.decode("latin-1"), "Name": names[int(m["src_seq"])],
@@ -98,7 +95,7 @@ def _orf_results(index, reads, names, o, seq_type):
                                                "PlusStrand": bool(m["plus_strand"]), "StartsAlternative": []},
                                   "Contig": ""},
                         "SearchResults": {"Hits": [{"Key": int(p), "Kmatch": int(k)}
-                                                   for p, k in zip(top.top_pid[i, :keep], top.top_kmatch[i, :keep])]}})
+                                                   for p, k in zip(top.top_pid[a:b], top.top_kmatch[a:b])]}})
         return out
     res = index.search(reads, seq_type=seq_type, want_positions=o.ExtractPositions)
     out = []

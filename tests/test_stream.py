@@ -37,6 +37,7 @@ def test_streamed_reads_equal_one_batch(klib, gpu_device):
     assert total["n_queries"] == ref.n_queries == len(cnt)
     assert total["n_lookup"] == ref.counters["n_lookup"] and total["n_hits"] == ref.counters["n_hits"]
     assert (cnt == ref.top_cnt).all()
+    rpid, rkm = ref.dense()
     for q in range(ref.n_queries):
         k = int(cnt[q])
-        assert pid[q, :k].tolist() == ref.top_pid[q, :k].tolist() and km[q, :k].tolist() == ref.top_kmatch[q, :k].tolist()
+        assert pid[q, :k].tolist() == rpid[q, :k].tolist() and km[q, :k].tolist() == rkm[q, :k].tolist()
