@@ -1366,7 +1366,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         tp.q_cap = ws->q_cap; tp.aa_cap = ws->aa_cap; tp.sa_cap = ws->sa_cap; tp.status = status;
         int tgrid = ws->n_cu * 8;  // 256-thread blocks, one (sequence, frame, piece) item per wave at a time
         tp.d_n6 = ws->d_n6;
-        int sgrid = ws->n_cu * 5;  // lane-per-read kernel: 2-wave blocks, ~31 KB of LDS each
+        int sgrid = ws->n_cu * 8;  // lane-per-read kernel: 2-wave blocks, 13 KB (COUNT) / 30 KB (WRITE) of LDS each
         if ((uint64_t)sgrid * TS_WAVES * 64 > (uint64_t)n_seqs) sgrid = n_seqs > 0 ? (int)(((uint64_t)n_seqs + TS_WAVES * 64 - 1) / (TS_WAVES * 64)) : 1;
         tp.n_long = ws->d_list_counts + SLOT_N_LONG;
         const size_t mpi = (size_t)ws->max_piece_items;
