@@ -15,7 +15,7 @@
 //   probe_kernel          the dominant kernel: flat over residue positions; sliding 7-mer
 //                         encode (k_store.go:91-117, search_protein.go:94-98) and bucket
 //                         probe (replaces KmerStore.Get, search.go:421) -> vals[pos]
-//   count_group_kernel    (count_group.hip.inc) postings expansion + Counter increments
+//   search_group_kernel    (count_group.hip.inc) postings expansion + Counter increments
 //                         (search.go:427-436, 442-452) in LDS hash tables, one 8-wave
 //                         workgroup per query group; a wave per query packs its table into
 //                         the query's hit list at E[q]
@@ -140,148 +140,116 @@ __device__ __forceinline__ void add_counter(unsigned long long *replicas, uint32
 }
 
 // ====================================================================================
-// Kernel P — flat probe over residue positions
+// The table as the kernels see it, and the lookup of one key
 // ====================================================================================
-// Position i of the packed residue buffer is a k-mer start iff bit (i & 63) of
-// valid[i >> 6] is set (prep clears the tail of every query and whole queries that are
-// too short).  One wave handles 64 consecutive positions: residue codes are staged in
-// LDS, each lane encodes its 7-mer (k_store.go:91-117 in closed form), then the wave
-// probes the bucket table with 4 lanes per 64-byte bucket (16 B each, one fabric
-// sector per probe) and writes one u32 per position:
-//     vals[i] = 0            key absent (or position not a k-mer start)
-//             = slot.val     key present: inline protein id or postings-list offset
-// This replaces KmerStore.GetValueFromBadger (search.go:421) for the whole batch at
-// once; the work is perfectly balanced whatever the query lengths are.
-struct ProbeParams {
-    const uint4 *table;  // buckets viewed as 4 x uint4 each
+// A lookup (replaces KmerStore.Get + KCombStore.Get, search.go:421-429) is ONE random 128-byte
+// request: the 8 cells of the key's home bucket.  In the counting kernel 8 adjacent lanes read
+// one bucket together (16 B each) and the lane whose cell matches already holds the key's first
+// three protein ids; a continuation cell (ids 3..5) sits in the next lane.  Only lists of more
+// than six ids need a second request (their tail lives in the arena).
+struct TableRef {
+    const uint4 *cells;   // n_buckets x KH_CELLS_PER_BUCKET cells of {key, w1, w2, w3}
+    const uint32_t *arena;
     uint64_t n_buckets;
     uint32_t n_shards, shard;
-    const uint8_t *residues;
-    unsigned long long *invalid;  // one bit per position, set = not a k-mer start; self-cleaning
-    const unsigned long long *d_n_pos;  // device scalar: number of residue positions
-    uint32_t *vals;
-    unsigned long long *counters;
-    uint32_t nontemporal;  // bucket loads bypass the caches (small batch against a large table)
+    uint32_t nontemporal;  // bucket loads bypass the caches (a small batch against a large table reads a bucket once)
 };
 
-#define P_WAVES 4
-
-__global__ __launch_bounds__(64 * P_WAVES) void probe_kernel(ProbeParams p)
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 load_cell(const uint4 *src, uint32_t nontemporal)
 {
-    __shared__ uint8_t s_lut[256];
-    __shared__ uint8_t s_stage[P_WAVES][80];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    const unsigned long long n_pos = *p.d_n_pos;
-    const unsigned long long n_win = (n_pos + 63) >> 6;
-    for (uint32_t i = tid; i < 256; i += 64 * P_WAVES) s_lut[i] = (uint8_t)kh_residue_code((uint8_t)i);
-    __syncthreads();  // the only workgroup barrier: the waves run independently from here on
-    uint32_t c_lookup = 0, c_probe = 0, c_found = 0;
-    uint8_t *stage = s_stage[wv];
+    const v4u *s = reinterpret_cast<const v4u *>(src);
+    const v4u t = nontemporal ? __builtin_nontemporal_load(s) : *s;
+    return make_uint4(t.x, t.y, t.z, t.w);
+}
 
-    const unsigned long long stride = (unsigned long long)gridDim.x * P_WAVES;
-    unsigned long long w = (unsigned long long)blockIdx.x * P_WAVES + wv;
-    // software pipeline: the bitmap word and the residues of the NEXT window are in flight
-    // while the buckets of the current one are fetched
-    unsigned long long mask = 0;
-    uint32_t ra = 0, rb = 0;
-    auto fetch = [&](unsigned long long win, unsigned long long &m, uint32_t &a, uint32_t &b) {
-        m = 0; a = 0; b = 0;
-        if (win < n_win) {
-            m = ~p.invalid[win];
-            const unsigned long long i0 = (win << 6) + lane;
-            if (i0 < n_pos) a = p.residues[i0];
-            if (lane < 6 && i0 + 64 < n_pos) b = p.residues[i0 + 64];
-        }
-    };
-    fetch(w, mask, ra, rb);
+__device__ __forceinline__ uint32_t table_home_bucket(const TableRef &t, uint32_t key)
+{
+    // kh_home_bucket with 32-bit multiplies (n_buckets < 2^32)
+    const uint32_t rest = kh_mix32(key) * t.n_shards;
+    return __umulhi(rest, (uint32_t)t.n_buckets);
+}
 
-    for (; w < n_win; w += stride) {
-        const unsigned long long base = w << 6;
-        unsigned long long nmask;
-        uint32_t na, nb;
-        fetch(w + stride, nmask, na, nb);
-        if (lane == 0 && mask != ~0ull) p.invalid[w] = 0ull;  // leave the bitmap clean for the next batch
+// The 7-mer that starts at byte `a` of the residue buffer, from the three aligned words that cover it
+// (d2 is only looked at when the window needs it), encoded like EncodeKmer (k_store.go:91-117).
+// `lut` maps a byte to its residue code (kh_residue_code) and lives in LDS.
+__device__ __forceinline__ uint32_t key_from_words(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t sh, const uint8_t *lut)
+{
+    const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh);  // residues 0..3
+    const uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, sh);  // residues 4..6 (+1)
+    return kh_key_from_codes(lut[lo & 0xFFu], lut[(lo >> 8) & 0xFFu], lut[(lo >> 16) & 0xFFu], lut[lo >> 24], lut[hi & 0xFFu],
+                             lut[(hi >> 8) & 0xFFu], lut[(hi >> 16) & 0xFFu]);
+}
+// the three words: residues a .. a+6 lie in bytes [a & ~3, (a & ~3) + 12); the third word is read
+// only when the window reaches into it, so nothing past the word that holds residue a+6 is touched.
+// `words` is the residue buffer rounded down to a 4-byte boundary and `a` counts from there (the
+// pointer must stay derived from the kernel argument: through an integer it would become a FLAT
+// pointer, and FLAT loads force vmcnt(0) waits on everything in flight).
+struct ResidueWords {
+    const uint32_t *words;
+    uint32_t mis;  // bytes between `words` and the first residue (0..3)
+};
+__device__ __forceinline__ ResidueWords residue_words(const uint8_t *residues)
+{
+    ResidueWords r;
+    r.mis = (uint32_t)(reinterpret_cast<uintptr_t>(residues) & 3u);
+    r.words = reinterpret_cast<const uint32_t *>(residues - r.mis);
+    return r;
+}
+__device__ __forceinline__ void load_kmer_words(const ResidueWords &rw, uint64_t a, uint32_t &d0, uint32_t &d1, uint32_t &d2, uint32_t &sh)
+{
+    a += rw.mis;
+    const uint32_t *w = rw.words + (a >> 2);
+    sh = (uint32_t)a & 3u;
+    d0 = w[0];
+    d1 = w[1];
+    d2 = w[sh >= 2u ? 2 : 1];
+}
 
-        uint32_t key = KH_EMPTY_KEY;
-        if (mask) {
-            stage[lane] = (base + lane < n_pos) ? s_lut[ra] : (uint8_t)KH_CODE_UNKNOWN;
-            if (lane < 6) stage[64 + lane] = (base + 64 + lane < n_pos) ? s_lut[rb] : (uint8_t)KH_CODE_UNKNOWN;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if ((mask >> lane) & 1ull) {
-                const uint8_t *st = stage + lane;
-                key = kh_key_from_codes(st[0], st[1], st[2], st[3], st[4], st[5], st[6]);
-                // sharded index: this device probes only the keys it owns
-                if (p.n_shards > 1 && kh_shard_of(key, p.n_shards) != p.shard) key = KH_EMPTY_KEY;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        }
-        const uint32_t bucket = (key != KH_EMPTY_KEY) ? (uint32_t)kh_home_bucket(key, p.n_shards, p.n_buckets) : 0u;
-
-        // round j serves the k-mers of lanes 16j..16j+15; lane 4g+j ends up owning k-mer 16j+g
-        uint4 ld[4];
-        uint32_t rkey[4], rbk[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int src = 16 * j + (int)(lane >> 2);
-            rbk[j] = __shfl(bucket, src, 64);
-            rkey[j] = __shfl(key, src, 64);
-            ld[j] = make_uint4(KH_EMPTY_KEY, 0, KH_EMPTY_KEY, 0);
-            // nontemporal when the batch is small against the table (a bucket is then read once per
-            // batch): keeping it out of the way of the lines the counting kernel re-reads (vals, list
-            // heads) is worth 8 us per 10 000-query batch downstream.  A 1 M-read batch touches every
-            // bucket several times and wants them cached (+9 % probe time when nontemporal).
-            if (rkey[j] != KH_EMPTY_KEY) {
-                typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-                const v4u *src = reinterpret_cast<const v4u *>(p.table) + (uint64_t)rbk[j] * 4 + (lane & 3u);
-                const v4u t = p.nontemporal ? __builtin_nontemporal_load(src) : *src;
-                ld[j] = make_uint4(t.x, t.y, t.z, t.w);
-            }
-        }
-        uint32_t okey = KH_EMPTY_KEY, oval = 0, obucket = 0;
-        bool oempty = true;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint32_t kk = rkey[j];
-            uint32_t r = (ld[j].x == kk) ? ld[j].y : ((ld[j].z == kk) ? ld[j].w : 0u);
-            uint32_t e = (ld[j].x == KH_EMPTY_KEY || ld[j].z == KH_EMPTY_KEY) ? 1u : 0u;
-            r |= __shfl_xor(r, 1, 64); e |= __shfl_xor(e, 1, 64);
-            r |= __shfl_xor(r, 2, 64); e |= __shfl_xor(e, 2, 64);
-            if ((lane & 3u) == (uint32_t)j) { okey = kk; oval = r; oempty = (e != 0u); obucket = rbk[j]; }
-        }
-        const bool valid = okey != KH_EMPTY_KEY;
-        if (valid) { c_lookup++; c_probe++; }
-        // rare: home bucket full and key not in it -> this lane walks the following buckets alone
-        if (valid && oval == 0u && !oempty) {
-            for (uint64_t tries = 1; tries < p.n_buckets; tries++) {
-                obucket = (obucket + 1u == (uint32_t)p.n_buckets) ? 0u : obucket + 1u;
-                c_probe++;
-                bool e = false;
-#pragma unroll
-                for (int s = 0; s < 4; s++) {
-                    const uint4 v = p.table[(uint64_t)obucket * 4 + s];
-                    if (v.x == okey) oval = v.y;
-                    if (v.z == okey) oval = v.w;
-                    e = e || v.x == KH_EMPTY_KEY || v.z == KH_EMPTY_KEY;
-                }
-                if (oval != 0u || e) break;
-            }
-        }
-        if (valid && oval != 0u) c_found++;
-        // the owner lane writes the position it owns: 16*(lane&3) + (lane>>2)
-        const unsigned long long opos = base + 16u * (lane & 3u) + (lane >> 2);
-        if (opos < n_pos) p.vals[opos] = valid ? oval : 0u;
-
-        mask = nmask; ra = na; rb = nb;
+// One lane looks a key up on its own (rare paths: the key's home bucket is full and does not hold it;
+// the G tier).  Returns the number of ids (0 = absent); c0 = the matching cell, c1 = its continuation.
+struct LaneHit {
+    uint32_t cnt;
+    uint4 c0, c1;
+};
+__device__ __forceinline__ uint32_t cell_count(const uint4 &c0, const uint4 &c1)
+{
+    if (c0.y & KH_ARENA_BIT) return c0.z;
+    uint32_t n = 1u + (c0.z != KH_NO_ID ? 1u : 0u) + ((c0.w & ~KH_CONT_BIT) != KH_NO_ID ? 1u : 0u);
+    if (c0.w & KH_CONT_BIT) n += 1u + (c1.z != KH_NO_ID ? 1u : 0u) + (c1.w != KH_NO_ID ? 1u : 0u);
+    return n;
+}
+// id t (t < cnt) of a hit
+__device__ __forceinline__ uint32_t hit_id(const TableRef &tab, const LaneHit &h, uint32_t t)
+{
+    if (h.c0.y & KH_ARENA_BIT) return t == 0u ? h.c0.w : tab.arena[(uint64_t)(h.c0.y & ~KH_ARENA_BIT) * 4 + (t - 1u)];
+    switch (t) {
+    case 0: return h.c0.y;
+    case 1: return h.c0.z;
+    case 2: return h.c0.w & ~KH_CONT_BIT;
+    case 3: return h.c1.y;
+    case 4: return h.c1.z;
+    default: return h.c1.w;
     }
-    const uint32_t t_lookup = wave_total(c_lookup), t_probe = wave_total(c_probe), t_found = wave_total(c_found);
-    if (lane == 0) {
-        const uint32_t rep = blockIdx.x * P_WAVES + wv;
-        add_counter(p.counters, rep, CTR_LOOKUP, t_lookup);
-        add_counter(p.counters, rep, CTR_PROBE, t_probe);
-        add_counter(p.counters, rep, CTR_FOUND, t_found);
+}
+__device__ __forceinline__ LaneHit lane_lookup(const TableRef &tab, uint32_t key, uint32_t bucket, uint32_t &n_probe)
+{
+    LaneHit h;
+    h.cnt = 0;
+    h.c0 = h.c1 = make_uint4(KH_EMPTY_KEY, 0, 0, 0);
+    for (uint64_t tries = 0; tries < tab.n_buckets; tries++) {
+        n_probe++;
+        const uint4 *cells = tab.cells + (uint64_t)bucket * KH_CELLS_PER_BUCKET;
+        uint4 c = cells[0];
+        for (int s = 0; s < KH_CELLS_PER_BUCKET; s++) {  // one cell at a time: few registers, the path is rare
+            const uint4 nx = s + 1 < KH_CELLS_PER_BUCKET ? cells[s + 1] : make_uint4(KH_EMPTY_KEY, 0, 0, 0);
+            if (c.x == key) { h.c0 = c; h.c1 = nx; h.cnt = cell_count(c, nx); return h; }
+            if (c.x == KH_EMPTY_KEY) return h;  // a bucket with a free cell ends the probe sequence
+            c = nx;
+        }
+        bucket = bucket + 1u == (uint32_t)tab.n_buckets ? 0u : bucket + 1u;
     }
+    return h;
 }
 
 // ====================================================================================
@@ -289,8 +257,8 @@ __global__ __launch_bounds__(64 * P_WAVES) void probe_kernel(ProbeParams p)
 // ====================================================================================
 struct QInfo;
 struct CountParams {
-    const uint32_t *arena;
-    const uint32_t *vals;  // from kernel P, indexed like the residue buffer
+    TableRef tab;
+    const uint8_t *residues;  // the protein records, or the ORF amino acids (4-byte aligned)
     // query groups (count_group.hip.inc)
     const struct QInfo *qinfo;
     const uint64_t *slot_off;   // exclusive scan of the table capacities
@@ -298,10 +266,10 @@ struct CountParams {
     const uint32_t *d_n_groups;
     const uint32_t *d_nq;
     uint32_t last_group_pass;   // this launch may clear group_first behind itself
-    // PositionHits pass (count_group_kernel MODE 1)
+    // PositionHits pass (search_group_kernel MODE 1)
     const uint64_t *pos_base;
     unsigned long long *pos_bits;
-    // merge of partial hit lists (count_group_kernel MODE 2)
+    // merge of partial hit lists (search_group_kernel MODE 2)
     const uint32_t *m_pid, *m_km, *m_fp;
     // tier input / overflow output lists
     const WorkItem *list;
@@ -429,135 +397,51 @@ __device__ __forceinline__ bool add_runs(const Table &tab, uint32_t x, uint32_t 
     return ok;
 }
 
-// NWIN 64-position windows of one query, processed by one wave with all their memory
-// round trips overlapped: (1) the probe results of every window, (2) the 16-byte heads of
-// every postings list (count + first three ids), (3) the remaining ids of all lists,
-// spread evenly over the 64 lanes whatever the individual list lengths are (per-window
-// prefix sum of the leftovers, owner found by binary search in LDS), then the counter
-// increments (KCombStore.Get + the id loop of search.go:427-436).  Window k starts at
-// c0 + k*stride.  `s_pref` is 64 words of LDS private to the wave.  No workgroup
-// barriers inside.  COUNT_ONLY: only sum the postings (G tier sizing pass).
-template <class Table, int NWIN, bool COUNT_ONLY>
-__device__ __forceinline__ bool count_windows(const CountParams &p, const uint32_t *vals,
-                                              int32_t size, int32_t c0, int32_t stride, const Table &tab, PostCtr &c,
-                                              volatile uint32_t *s_pref)
+// G tier: one 64-position window of ONE query per call.  Every lane looks its own key up
+// (lane_lookup: the bucket's cells one lane at a time -- the G tier is rare, the cooperative 8-lane
+// probe lives in the group kernel), then the counter increments (KCombStore.Get + the id loop of
+// search.go:427-436): first ids with run merging, short lists lane by lane, long lists (arena)
+// spread over the whole wave.  No workgroup barriers inside.  COUNT_ONLY: only sum the postings
+// (G tier sizing pass).  `lut`: byte -> residue code, in LDS.
+template <class Table, bool COUNT_ONLY>
+__device__ __forceinline__ bool count_window(const CountParams &p, uint64_t aa_off, int32_t size, int32_t c0, const Table &tab,
+                                             PostCtr &c, const uint8_t *lut)
 {
     const uint32_t lane = lane_id();
-    uint32_t v[NWIN];
-    uint4 h[NWIN];
-#pragma unroll
-    for (int k = 0; k < NWIN; k++) {
-        const int32_t pos = c0 + k * stride + (int32_t)lane;
-        v[k] = 0u;
-        h[k] = make_uint4(0, 0, 0, 0);
-        if (pos < size) {
-            v[k] = vals[pos];
-            if (v[k] & KH_INLINE_BIT) h[k] = make_uint4(1u, v[k] & ~KH_INLINE_BIT, 0, 0);
-            else if (v[k] != 0u) h[k] = reinterpret_cast<const uint4 *>(p.arena)[v[k]];  // {count, id0, id1, id2}
-        }
+    const int32_t pos = c0 + (int32_t)lane;
+    LaneHit h;
+    h.cnt = 0;
+    h.c0 = h.c1 = make_uint4(KH_EMPTY_KEY, 0, 0, 0);
+    if (pos < size) {
+        uint32_t d0, d1, d2, sh, np = 0;
+        load_kmer_words(residue_words(p.residues), aa_off + (uint64_t)pos, d0, d1, d2, sh);
+        const uint32_t key = key_from_words(d0, d1, d2, sh, lut);
+        if (!(p.tab.n_shards > 1 && kh_shard_of(key, p.tab.n_shards) != p.tab.shard))
+            h = lane_lookup(p.tab, key, table_home_bucket(p.tab, key), np);
     }
+    const bool arena = (h.c0.y & KH_ARENA_BIT) != 0u && h.cnt != 0u;
+    if (h.cnt != 0u) {
+        c.post += h.cnt;
+        if (arena) { c.lists++; c.lids += h.cnt - 1u; }
+    }
+    if (COUNT_ONLY) return true;
     bool ok = true;
     uint32_t nnew = 0;
-    // leftovers (ids beyond the three that came with the head): all their loads are issued
-    // before anything is consumed
-    constexpr int XIT = 2;  // leftover rounds kept in registers per window (64 ids each)
-    uint32_t xid[NWIN][XIT], xpos[NWIN][XIT];
-    uint32_t xtotal[NWIN];
-    if (!COUNT_ONLY) {
-#pragma unroll
-        for (int k = 0; k < NWIN; k++) {
-            const uint32_t lcnt = h[k].x;
-            const uint32_t extra = lcnt > 3u ? lcnt - 3u : 0u;
-            uint32_t inc = extra;  // inclusive prefix over the wave
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t t = __shfl_up(inc, o, 64);
-                if ((int)lane >= o) inc += t;
-            }
-            xtotal[k] = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-            s_pref[k * 64 + lane] = inc - extra;  // exclusive prefix
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int k = 0; k < NWIN; k++) {
-            const volatile uint32_t *pref = s_pref + k * 64;
-#pragma unroll
-            for (int it = 0; it < XIT; it++) {
-                const uint32_t t = (uint32_t)it * 64u + lane;
-                const bool act = t < xtotal[k];
-                uint32_t lo = 0;
-                if (act) {  // largest lane with pref[lane] <= t owns leftover t
-#pragma unroll
-                    for (int sft = 32; sft > 0; sft >>= 1)
-                        if (pref[lo + sft] <= t) lo += sft;
-                }
-                // executed by all lanes: the owner may be a lane that is idle in this round
-                const uint32_t off = __shfl(v[k], (int)lo, 64);
-                xid[k][it] = KH_EMPTY_PID;
-                xpos[k][it] = (uint32_t)(c0 + k * stride) + lo;
-                if (act) xid[k][it] = p.arena[(uint64_t)off * 4 + 4 + (t - pref[lo])];
-            }
-        }
-        // very long lists (more than XIT*64 leftovers in one window): counted as they arrive
-#pragma unroll
-        for (int k = 0; k < NWIN; k++) {
-            const volatile uint32_t *pref = s_pref + k * 64;
-            for (uint32_t t0 = XIT * 64u; t0 < xtotal[k]; t0 += 64) {
-                const uint32_t t = t0 + lane;
-                const bool act = t < xtotal[k];
-                uint32_t lo = 0;
-                if (act) {
-#pragma unroll
-                    for (int sft = 32; sft > 0; sft >>= 1)
-                        if (pref[lo + sft] <= t) lo += sft;
-                }
-                const uint32_t off = __shfl(v[k], (int)lo, 64);
-                if (act) ok = ok && tab.add_n(p.arena[(uint64_t)off * 4 + 4 + (t - pref[lo])], (uint32_t)(c0 + k * stride) + lo, 1u, nnew);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+    ok = add_runs(tab, h.cnt != 0u ? hit_id(p.tab, h, 0u) : KH_EMPTY_PID, (uint32_t)pos, nnew);
+    constexpr uint32_t SERIAL = 8;  // ids a lane adds on its own; the rest of a longer list is shared by the wave
+    const uint32_t n_ser = h.cnt < SERIAL ? h.cnt : SERIAL;
+    for (uint32_t t = 1; t < n_ser; t++) ok = tab.add_n(hit_id(p.tab, h, t), (uint32_t)pos, 1u, nnew) && ok;
+    unsigned long long big = __ballot(h.cnt > SERIAL);
+    while (big) {
+        const int l = __ffsll((long long)big) - 1;
+        big &= big - 1ull;
+        const uint32_t cnt_l = __shfl(h.cnt, l, 64), off_l = __shfl(h.c0.y & ~KH_ARENA_BIT, l, 64), pos_l = (uint32_t)c0 + (uint32_t)l;
+        for (uint32_t t = SERIAL + lane; t < cnt_l; t += 64)
+            ok = tab.add_n(p.tab.arena[(uint64_t)off_l * 4 + (t - 1u)], pos_l, 1u, nnew) && ok;
     }
-    // heads: inline ids and the first three ids of every list
-#pragma unroll
-    for (int k = 0; k < NWIN; k++) {
-        const uint32_t pos = (uint32_t)(c0 + k * stride) + lane;
-        const uint32_t lcnt = h[k].x;
-        if (lcnt != 0u) {
-            c.post += lcnt;
-            if (!(v[k] & KH_INLINE_BIT)) { c.lists++; c.lids += lcnt; }
-        }
-        if (!COUNT_ONLY) {  // all lanes take part: run heads add for their whole run
-            ok = add_runs(tab, lcnt > 0 ? h[k].y : KH_EMPTY_PID, pos, nnew) && ok;
-            ok = add_runs(tab, lcnt > 1 ? h[k].z : KH_EMPTY_PID, pos, nnew) && ok;
-            ok = add_runs(tab, lcnt > 2 ? h[k].w : KH_EMPTY_PID, pos, nnew) && ok;
-        }
-    }
-    if (!COUNT_ONLY) {
-#pragma unroll
-        for (int k = 0; k < NWIN; k++)
-#pragma unroll
-            for (int it = 0; it < XIT; it++)
-                if (xid[k][it] != KH_EMPTY_PID) ok = ok && tab.add_n(xid[k][it], xpos[k][it], 1u, nnew);
-        const uint32_t wave_new = wave_total(nnew);
-        if (lane == 0 && wave_new) atomicAdd(tab.nd, wave_new);
-    }
+    const uint32_t wave_new = wave_total(nnew);
+    if (lane == 0 && wave_new) atomicAdd(tab.nd, wave_new);
     return __all(ok);
-}
-
-// sets bits [b, e) of the not-a-k-mer-start bitmap
-__device__ __forceinline__ void mark_invalid_range(unsigned long long *invalid, uint64_t b, uint64_t e)
-{
-    // sets bits [b, e)
-    while (b < e) {
-        const uint64_t w = b >> 6;
-        const uint64_t hi = ((w + 1) << 6) < e ? ((w + 1) << 6) : e;
-        const unsigned nb = (unsigned)(hi - b);
-        const unsigned long long m = (nb == 64 ? ~0ull : ((1ull << nb) - 1ull)) << (b & 63);
-        atomicOr(&invalid[w], m);
-        b = hi;
-    }
 }
 
 #include "count_group.hip.inc"
@@ -601,11 +485,11 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
 {
     constexpr int WAVES = G_WAVES;
     __shared__ uint32_t s_nd, s_fail, s_cursor;
-    constexpr int NWIN = 2;
-    __shared__ uint32_t s_pref[WAVES][NWIN * 64];
+    __shared__ uint8_t s_lut[256];
     __shared__ unsigned long long s_post, s_off, s_base;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    for (uint32_t i = tid; i < 256; i += 64 * WAVES) s_lut[i] = (uint8_t)kh_residue_code((uint8_t)i);
     const uint32_t n_items = *p.list_count < p.list_cap ? *p.list_count : p.list_cap;
     unsigned long long tot_hits = 0;
     PostCtr pc;
@@ -616,13 +500,12 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
         const WorkItem wi = p.list[item];
         const uint32_t q = wi.q;
         const int32_t size = wi.size;
-        const uint32_t *vals = p.vals + wi.aa_off;
         if (tid == 0) { s_nd = 0; s_fail = 0; s_post = 0; s_cursor = 0; }
         __syncthreads();
         // pass 1: exact number of postings (an upper bound of the distinct proteins)
         pc.clear();
-        for (int32_t r0 = 0; r0 < size; r0 += 64 * WAVES * NWIN)
-            count_windows<NullTable, NWIN, true>(p, vals, size, r0 + 64 * (int32_t)wv, 64 * WAVES, nt, pc, s_pref[wv]);
+        for (int32_t r0 = 64 * (int32_t)wv; r0 < size; r0 += 64 * WAVES)
+            count_window<NullTable, true>(p, wi.aa_off, size, r0, nt, pc, s_lut);
         {
             const unsigned long long wp = wave_total(pc.post);
             if (lane == 0 && wp) atomicAdd(&s_post, wp);
@@ -658,9 +541,8 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
         __syncthreads();
         // pass 2: count
         pc.clear();
-        for (int32_t r0 = 0; r0 < size; r0 += 64 * WAVES * NWIN) {
-            const bool ok = count_windows<GlobalTable, NWIN, false>(p, vals, size, r0 + 64 * (int32_t)wv, 64 * WAVES, gt,
-                                                                   pc, s_pref[wv]);
+        for (int32_t r0 = 64 * (int32_t)wv; r0 < size; r0 += 64 * WAVES) {
+            const bool ok = count_window<GlobalTable, false>(p, wi.aa_off, size, r0, gt, pc, s_lut);
             if (!ok) s_fail = 1;
         }
         __syncthreads();
@@ -743,11 +625,11 @@ struct BitsTable {
 __global__ __launch_bounds__(64 * G_WAVES) void positions_global_kernel(CountParams p)
 {
     constexpr int WAVES = G_WAVES;
-    constexpr int NWIN = 2;
     __shared__ uint32_t s_nd;
-    __shared__ uint32_t s_pref[WAVES][NWIN * 64];
+    __shared__ uint8_t s_lut[256];
     __shared__ unsigned long long s_off;
     const uint32_t tid = threadIdx.x, wv = tid >> 6;
+    for (uint32_t i = tid; i < 256; i += 64 * WAVES) s_lut[i] = (uint8_t)kh_residue_code((uint8_t)i);
     const uint32_t n_items = *p.list_count < p.list_cap ? *p.list_count : p.list_cap;
     PostCtr pc;
     for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
@@ -784,8 +666,8 @@ __global__ __launch_bounds__(64 * G_WAVES) void positions_global_kernel(CountPar
         bt.bits = p.pos_bits + p.pos_base[q];
         pc.clear();
         bool ok = true;
-        for (int32_t r0 = 0; r0 < size; r0 += 64 * WAVES * NWIN)
-            ok = count_windows<BitsTable, NWIN, false>(p, p.vals + wi.aa_off, size, r0 + 64 * (int32_t)wv, 64 * WAVES, bt, pc, s_pref[wv]) && ok;
+        for (int32_t r0 = 64 * (int32_t)wv; r0 < size; r0 += 64 * WAVES)
+            ok = count_window<BitsTable, false>(p, wi.aa_off, size, r0, bt, pc, s_lut) && ok;
         if (!ok && (tid & 63u) == 0) atomicOr(p.status, (uint32_t)ST_G_TABLE_FULL);
         __syncthreads();
     }
@@ -952,8 +834,6 @@ struct kaamer_workspace {
     kaamer_query_meta *d_q;
     uint32_t *d_nq;
     unsigned long long *d_n_pos;
-    unsigned long long *d_valid;        // one bit per residue position
-    uint32_t *d_vals;                   // probe result per residue position
     uint32_t *d_q_cnt;
     unsigned long long *d_pool_cursor;  // CURSOR_STRIDE apart: G-tier tail cursor, G arena cursor (count), G arena cursor (positions)
     WorkItem *d_lists;                  // [N_LISTS][q_cap] (only the G tier's overflow list is used)
@@ -1029,16 +909,16 @@ template <class T> static int dev_alloc(T **p, size_t n)
 
 static void launch_group(const CountParams &p, int grid, bool firstpos, hipStream_t s)
 {
-    if (firstpos) hipLaunchKernelGGL((count_group_kernel<true, 0>), dim3(grid), dim3(64 * GRP_WAVES), 0, s, p);
-    else hipLaunchKernelGGL((count_group_kernel<false, 0>), dim3(grid), dim3(64 * GRP_WAVES), 0, s, p);
+    if (firstpos) hipLaunchKernelGGL((search_group_kernel<true, 0>), dim3(grid), dim3(64 * GRP_WAVES), 0, s, p);
+    else hipLaunchKernelGGL((search_group_kernel<false, 0>), dim3(grid), dim3(64 * GRP_WAVES), 0, s, p);
 }
 static void launch_group_positions(const CountParams &p, int grid, hipStream_t s)
 {
-    hipLaunchKernelGGL((count_group_kernel<false, 1>), dim3(grid), dim3(64 * GRP_WAVES), 0, s, p);
+    hipLaunchKernelGGL((search_group_kernel<false, 1>), dim3(grid), dim3(64 * GRP_WAVES), 0, s, p);
 }
 static void launch_group_merge(const CountParams &p, int grid, hipStream_t s)
 {
-    hipLaunchKernelGGL((count_group_kernel<true, 2>), dim3(grid), dim3(64 * GRP_WAVES), 0, s, p);
+    hipLaunchKernelGGL((search_group_kernel<true, 2>), dim3(grid), dim3(64 * GRP_WAVES), 0, s, p);
 }
 
 extern "C" {
@@ -1102,7 +982,7 @@ void kaamer_workspace_free(kaamer_workspace *ws)
 {
     if (!ws) return;
     (void)hipSetDevice(ws->device);
-    void *bufs[] = { ws->d_q, ws->d_nq, ws->d_n_pos, ws->d_valid, ws->d_vals, ws->d_cnt3, ws->d_off3, ws->d_n6, ws->d_long_seq, ws->d_long_np, ws->d_pcnt3, ws->d_n_piece_items, ws->d_piece_base, ws->d_poff3,
+    void *bufs[] = { ws->d_q, ws->d_nq, ws->d_n_pos, ws->d_cnt3, ws->d_off3, ws->d_n6, ws->d_long_seq, ws->d_long_np, ws->d_pcnt3, ws->d_n_piece_items, ws->d_piece_base, ws->d_poff3,
                      ws->d_tmp_meta, ws->d_orf_aa, ws->d_starts_alt, ws->d_q_cnt, ws->d_csr_off, ws->d_c_pid, ws->d_c_km, ws->d_c_fp,
                      ws->d_pool_cursor, ws->d_lists, ws->d_list_counts, ws->d_status_out, ws->d_qinfo, ws->d_slots,
                      ws->d_slot_off, ws->d_group_first, ws->d_n_groups, ws->d_pos_words, ws->d_pos_base, ws->d_pos_off, ws->d_pos_bits, ws->d_g_keys,
@@ -1137,7 +1017,9 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
         ws->q_cap = (uint32_t)qc;
         ws->pos_cap = ws->aa_cap + 64;
     } else {
-        ws->q_cap = opts->max_queries ? opts->max_queries : ws->max_seqs;
+        // one query per protein record: never fewer slots than sequences (the prep kernel writes one
+        // descriptor per sequence)
+        ws->q_cap = opts->max_queries > ws->max_seqs ? opts->max_queries : ws->max_seqs;
         ws->pos_cap = opts->max_seq_bytes + 64;
     }
     if (ws->q_cap < 1) ws->q_cap = 1;
@@ -1151,21 +1033,18 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     }
     // the reference fills PositionHits only for nucleotide/reads input or with -pos (search.go:416)
     ws->firstpos = opts->first_pos == 1 || (opts->first_pos == 0 && (opts->seq_type == KAAMER_NUCLEOTIDE || opts->seq_type == KAAMER_READS));
-    int grp_per_cu = 0, p_per_cu = 0;
+    int grp_per_cu = 0;
     hipError_t oe = ws->firstpos
-        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&grp_per_cu, count_group_kernel<true, 0>, 64 * GRP_WAVES, 0)
-        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&grp_per_cu, count_group_kernel<false, 0>, 64 * GRP_WAVES, 0);
-    if (oe == hipSuccess) oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&p_per_cu, probe_kernel, 64 * P_WAVES, 0);
+        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&grp_per_cu, search_group_kernel<true, 0>, 64 * GRP_WAVES, 0)
+        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&grp_per_cu, search_group_kernel<false, 0>, 64 * GRP_WAVES, 0);
     if (oe != hipSuccess) { delete ws; return kaamer_fail(KAAMER_E_HIP, "occupancy query: %s", hipGetErrorString(oe)); }
     hipDeviceProp_t prop;
     hipError_t pe = hipGetDeviceProperties(&prop, ix->device);
     if (pe != hipSuccess) { delete ws; return kaamer_fail(KAAMER_E_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(pe)); }
     if (grp_per_cu < 1) grp_per_cu = 1;
-    if (p_per_cu < 1) p_per_cu = 1;
     ws->n_cu = prop.multiProcessorCount;
     ws->grp_grid = ws->n_cu * grp_per_cu;
     ws->g_grid = ws->n_cu / 2;  // the G tier is rare; its last workgroup also finalizes the batch (one atomic per workgroup)
-    ws->p_grid = ws->n_cu * p_per_cu;
     // a table has at most max(64, 3 x SizeInKmer) slots
     {
         const uint64_t gc = ((uint64_t)GRP_MIN_TABLE * ws->q_cap + 3 * ws->pos_cap) / GRP_BUDGET + 4;
@@ -1186,8 +1065,6 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     rc = dev_alloc(&ws->d_q, ws->q_cap);
     if (!rc) rc = dev_alloc(&ws->d_nq, 1);
     if (!rc) rc = dev_alloc(&ws->d_n_pos, 1);
-    if (!rc) rc = dev_alloc(&ws->d_valid, (size_t)(ws->pos_cap / 64 + 2));
-    if (!rc) rc = dev_alloc(&ws->d_vals, (size_t)ws->pos_cap);
     if (!rc && ws->nucleotide) {
         const size_t n6 = (size_t)ws->max_seqs * 6;
         rc = dev_alloc(&ws->d_cnt3, 3 * n6);
@@ -1327,7 +1204,6 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         HIPCHK(hipMemsetAsync(ws->d_pool_cursor, 0, (size_t)3 * CURSOR_STRIDE * sizeof(unsigned long long), s));
         HIPCHK(hipMemsetAsync(ws->d_list_counts, 0, N_SMALL_SLOTS * sizeof(uint32_t), s));
         HIPCHK(hipMemsetAsync(ws->d_counter_replicas, 0, sizeof(unsigned long long) * CTR_REPLICAS * CTR_N, s));
-        HIPCHK(hipMemsetAsync(ws->d_valid, 0, (size_t)(ws->pos_cap / 64 + 2) * sizeof(unsigned long long), s));
     }
     ws->clean = false;
 
@@ -1342,7 +1218,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         PrepLayoutParams pl;
         memset(&pl, 0, sizeof pl);
         pl.seqs = d_seqs; pl.offsets = d_offsets; pl.n_seqs = n_seqs;
-        pl.q = ws->d_q; pl.d_nq = ws->d_nq; pl.d_n_pos = ws->d_n_pos; pl.invalid = ws->d_valid; pl.qinfo = ws->d_qinfo;
+        pl.q = ws->d_q; pl.d_nq = ws->d_nq; pl.d_n_pos = ws->d_n_pos; pl.qinfo = ws->d_qinfo;
         pl.hit_off = ws->d_hit_off; pl.q_cnt = ws->d_q_cnt;
         pl.E = ws->d_slot_off; pl.group_first = ws->d_group_first; pl.group_start = ws->d_group_start;
         pl.d_n_groups = ws->d_n_groups; pl.groups_cap = ws->groups_cap; pl.chain = ws->d_chain;
@@ -1412,7 +1288,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         hipLaunchKernelGGL(translate_short_kernel<true>, dim3(sgrid), dim3(64 * TS_WAVES), 0, s, tp);
         hipLaunchKernelGGL(orf_order_kernel, dim3(ws->n_cu * 4), dim3(256), 0, s, ws->d_tmp_meta, tp.off_orf, n_seqs, ws->d_q,
                            ws->d_nq, ws->d_n_pos, tp.off_aa, (uint64_t)ws->q_cap, status);
-        hipLaunchKernelGGL(prep_orf_kernel, dim3(ws->n_cu * 4), dim3(pb), 0, s, ws->d_q, ws->d_nq, ws->d_valid, ws->d_n_pos,
+        hipLaunchKernelGGL(prep_orf_kernel, dim3(ws->n_cu * 4), dim3(pb), 0, s, ws->d_q, ws->d_nq,
                            ws->d_qinfo, ws->d_slots, ws->d_hit_off, ws->d_q_cnt);
         residues = ws->d_orf_aa;
         pos_bound = ws->aa_cap;
@@ -1422,29 +1298,19 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     // ---- query groups: table layout, first query of each group, schedule (protein: done with the prep)
     if (nucl) launch_layout(ws, nq_bound, status, s);
 
-    // ---- kernel P: flat probe
-    ProbeParams pp;
-    pp.table = reinterpret_cast<const uint4 *>(ix->d_buckets);
-    pp.n_buckets = ix->hdr.n_buckets;
-    pp.n_shards = ix->hdr.n_shards;
-    pp.shard = ix->hdr.shard;
-    pp.residues = residues;
-    pp.invalid = ws->d_valid;
-    pp.d_n_pos = ws->d_n_pos;
-    pp.vals = ws->d_vals;
-    pp.counters = ws->d_counter_replicas;
-    pp.nontemporal = pos_bound < ix->hdr.n_buckets ? 1u : 0u;
-    uint64_t p_blocks = (pos_bound / 64 + 1 + P_WAVES - 1) / P_WAVES;
-    if (p_blocks > (uint64_t)ws->p_grid) p_blocks = ws->p_grid;
-    if (p_blocks < 1) p_blocks = 1;
     if (timed) HIPCHK(hipEventRecord(ev[1], s));
-    hipLaunchKernelGGL(probe_kernel, dim3((unsigned)p_blocks), dim3(64 * P_WAVES), 0, s, pp);
-    if (timed) HIPCHK(hipEventRecord(ev[2], s));
-    // ---- kernel C: counting
+    // ---- the search kernel: probe + count
     CountParams p;
     memset(&p, 0, sizeof p);
-    p.arena = ix->d_arena;
-    p.vals = ws->d_vals;
+    p.tab.cells = reinterpret_cast<const uint4 *>(ix->d_buckets);
+    p.tab.arena = ix->d_arena;
+    p.tab.n_buckets = ix->hdr.n_buckets;
+    p.tab.n_shards = ix->hdr.n_shards;
+    p.tab.shard = ix->hdr.shard;
+    // nontemporal when the batch is small against the table (a bucket is then read once per batch); a
+    // 1 M-read batch touches every bucket several times and wants them cached
+    p.tab.nontemporal = pos_bound < ix->hdr.n_buckets ? 1u : 0u;
+    p.residues = residues;
     p.qinfo = ws->d_qinfo;
     p.slot_off = ws->d_slot_off;
     p.group_first = ws->d_group_first;
@@ -1483,6 +1349,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         grp_blocks = gb;
         launch_group(pc, (int)gb, ws->firstpos, s);
     }
+    if (timed) HIPCHK(hipEventRecord(ev[2], s));
     CountParams pg = p;
     pg.list = list_ptr(LIST_G); pg.list_count = ws->d_list_counts + LIST_G;
     int g_grid = ws->g_grid;
@@ -1563,7 +1430,6 @@ int kaamer_merge_device(kaamer_workspace *ws, const uint64_t *d_ent_off, const u
         HIPCHK(hipMemsetAsync(ws->d_pool_cursor, 0, (size_t)3 * CURSOR_STRIDE * sizeof(unsigned long long), s));
         HIPCHK(hipMemsetAsync(ws->d_list_counts, 0, N_SMALL_SLOTS * sizeof(uint32_t), s));
         HIPCHK(hipMemsetAsync(ws->d_counter_replicas, 0, sizeof(unsigned long long) * CTR_REPLICAS * CTR_N, s));
-        HIPCHK(hipMemsetAsync(ws->d_valid, 0, (size_t)(ws->pos_cap / 64 + 2) * sizeof(unsigned long long), s));
     }
     ws->clean = false;
     uint32_t *status = ws->d_list_counts + SLOT_STATUS;

@@ -51,6 +51,10 @@ static void ko_build_tables(void)
         unsigned a = (unsigned char)aa[j];
         g_single[a] = (uint32_t)j;                     /* k_store.go:49-51 */
         g_single_set[a] = 1;
+        /* aaTable[{a,'.'}] = j is an ordinary map entry: the PAIR lookup of
+         * EncodeKmer (k_store.go:102-103) also finds it when the second letter
+         * of a pair is '.', e.g. "C.AAAAA" -> 0x008582C0. */
+        g_pair[a][(unsigned char)'.'] = (uint32_t)j;
         for (int b = 0; b < 21; b++) {
             g_pair[a][(unsigned char)aa[b]] = i;       /* k_store.go:54-56 */
             i++;                                       /* k_store.go:58 */

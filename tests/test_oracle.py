@@ -15,7 +15,11 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 KATS = [("AAAAAAA", 0x0B0582C0), ("YYYYYYY", 0xE773B9D4), ("MELPNIM", 0x75B7E08A),
         ("ACDEFGH", 0x0B90CDE6), ("XAAAAAA", 0x000582C0), ("UUUUUUU", 0xC6633191),
         ("MKVLAAG", 0x786642C5), ("AAAAAAX", 0x0B0582C0), ("AAAAAA*", 0x0B0582C0),
-        ("XXXXXXX", 0x00000000), ("aaaaaaa", 0x00000000), ("AXAAAAA", 0x000582C0)]
+        ("XXXXXXX", 0x00000000), ("aaaaaaa", 0x00000000), ("AXAAAAA", 0x000582C0),
+        # aaTable[{a,'.'}] = j (k_store.go:48-52) is also found by the PAIR lookup (k_store.go:102-103):
+        # a pair whose second letter is '.' encodes as the index of its first letter
+        ("C.AAAAA", 0x008582C0), ("Y.Y.Y.Y", 0x0A050294), ("A.AAAAA", 0x000582C0), (".AAAAAA", 0x000582C0),
+        ("AAAAAA.", 0x0B0582C0), ("AA..AAA", 0x0B0002C0), ("AAAAY.A", 0x0B058280)]
 
 ORF_KAT_READ = ("GCTAAAGACAATTACATAACATACACGTCAGCACGAAACTTGTTGGCCCAGTGTGAATCGCTTAAGGGTTAAGTAAGTGTGATGCATACGCC"
                 "TTTACTTGCTGTGTCCACCCCATCGGACTGGCATTTTTATTACACTCAGAAACAGAAC")
@@ -45,6 +49,51 @@ def test_codec_roundtrip_and_random(oracle):
     for _ in range(2000):
         k = "".join(rng.choice(noisy) for _ in range(7))
         assert oracle.encode_kmer(k) == pyref.encode_kmer(k)
+
+
+def test_codec_all_bytes_every_position(oracle, klib):
+    """oracle == pyref == the product's kaamer_encode_kmer for every byte value in every position and,
+    exhaustively, for every byte PAIR in each of the three pair positions (k_store.go:100-110)."""
+    base = bytearray(b"MKVLAAG")
+    for pos in range(7):
+        for b in range(256):
+            k = bytes(base[:pos]) + bytes([b]) + bytes(base[pos + 1:])
+            e = pyref.encode_kmer(k)
+            assert oracle.encode_kmer(k) == e, (pos, b)
+            assert klib.kaamer_encode_kmer(k) == e, (pos, b)
+    # pyref's table as arrays, so the 3 x 65 536 pair sweep compares two C implementations against it cheaply
+    pair = np.zeros((256, 256), np.uint32)
+    for (a, b), v in pyref._AA_TABLE.items():
+        pair[ord(a), ord(b)] = v
+    for s, sh in ((0, 23), (2, 14), (4, 5)):
+        rest = pyref.encode_kmer(bytes(base)) & ~(0x1FF << sh) & 0xFFFFFFFF
+        for a in range(256):
+            for b in range(256):
+                k = bytes(base[:s]) + bytes([a, b]) + bytes(base[s + 2:])
+                e = rest | (int(pair[a, b]) << sh)
+                assert oracle.encode_kmer(k) == e, (s, a, b)
+                assert klib.kaamer_encode_kmer(k) == e, (s, a, b)
+    rng = random.Random(5)
+    for _ in range(20000):  # and random byte soup, '.' over-represented
+        k = bytes(rng.choice(b"ACDEFGHIKLMNPQRSTUVWY....XBZ*a") if rng.random() < 0.8 else rng.randrange(256) for _ in range(7))
+        e = pyref.encode_kmer(k)
+        assert oracle.encode_kmer(k) == e and klib.kaamer_encode_kmer(k) == e, k
+
+
+def test_gcode_all_bytes(oracle):
+    """gcodeBacteria is a map keyed by the lower-cased codon string (dna.go:68,106): any byte other than
+    t/c/a/g in any position is a map miss -> AminoAcid{} ("", false, false).  All 256 values, every position."""
+    table = json.load(open(os.path.join(GOLD, "gcode_bacteria.json")))
+    for pos in range(3):
+        for b in range(256):
+            for rest in ("tt", "ca", "ag", "gg", "at", "tg"):
+                codon = bytearray(rest[:pos].encode() + bytes([b]) + rest[pos:].encode())
+                exp = ("", False, False)
+                txt = codon.decode("latin-1")
+                if txt in table:
+                    exp = tuple(table[txt])
+                assert oracle.gcode_bacteria(bytes(codon)) == exp, codon
+                assert pyref.GCODE_BACTERIA.get(txt, ("", False, False)) == exp
 
 
 def test_gcode_matches_reference_text(oracle):
