@@ -2,16 +2,24 @@
 """bench.py — headline benchmark of the kaamer k-mer search path on MI355X.
 
 Metric (BASELINE.json): k-mer lookups/sec (+ query seqs/sec) and the fraction of
-the HBM-bandwidth roofline.  One "step" = one pass of the hot path (prep ->
-probe/count kernel -> scan -> gather) over one batch of synthetic queries that
-is already resident in HBM.
+the HBM-bandwidth roofline.
 
 N = 1 workload: BASELINE.json configs[1] — Swiss-Prot-sized synthetic DB
-(560 000 proteins, ~2e8 residues) resident in one MI355X, 10 000 protein
-queries per batch (seed 20261003).
+(560 000 proteins, ~2e8 residues) resident in one MI355X, batches of 10 000
+protein queries (seed 20261003), inputs resident in HBM.
+
+One STEP = `--batches-per-step` batches (default 200 x 10 000 protein queries, or
+3 x 1 M reads) pushed back to back through the hot path (prep -> search kernel
+[probe + count] -> G tier/finalize), rotating over `--distinct-batches` different
+pre-generated batches so that consecutive batches touch different buckets (one
+batch reads ~0.46 GB of buckets, the Infinity Cache holds 0.27 GB, the table is
+4 GB).  A step therefore lasts ~25 ms and the driver's 20 steps give a 0.5 s
+timed region; lookups/s does not depend on how batches are grouped into steps.
+
 N > 1: the DB fits one GPU, so ranks are replicas (no data-path collective):
-every rank holds the table and searches its own batch of 10 000 queries;
-value = all ranks' lookups / max-over-ranks time ("weak").
+every rank holds the table and searches its own batches; value = all ranks'
+lookups / max-over-ranks time ("weak").  `--mode sharded` runs the hash-prefix
+sharded index of configs[3] instead (one exchange step per batch).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -45,13 +53,21 @@ def log(*a):
         print("[bench]", *a, file=sys.stderr, flush=True)
 
 
+def host_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except Exception:
+        return os.cpu_count() or 1
+
+
 def cpu_baseline(oix, queries, seconds=12.0, threads=None, kind="protein"):
     """The CPU restatement of the reference algorithm (oracle/, kind "port"),
     multi-threaded across queries like the reference's nbOfThreads workers
-    (search_protein.go:58), on a bounded sample of the same batch."""
+    (search_protein.go:58; the reference's default is runtime.NumCPU(), api/server.go:55-59),
+    on a bounded sample of the same batch, on every host core this process may use."""
     from concurrent.futures import ThreadPoolExecutor
     nq = len(queries[1]) - 1
-    threads = threads or min(os.cpu_count() or 1, 16)
+    threads = threads or host_cores()
     block = 25
     t_start = time.time()
 
@@ -63,6 +79,8 @@ def cpu_baseline(oix, queries, seconds=12.0, threads=None, kind="protein"):
         while time.time() - t_start < seconds:
             if b >= nq:
                 b = tid * block
+                if b >= nq:
+                    break
             e = min(nq, b + block)
             r = oix.batch(queries, kind, b, e)   # ctypes releases the GIL
             lookups += r["n_lookup"]
@@ -76,7 +94,7 @@ def cpu_baseline(oix, queries, seconds=12.0, threads=None, kind="protein"):
     lookups = sum(p[0] for p in parts)
     nqd = sum(p[1] for p in parts)
     return {"value": lookups / dt, "unit": "k-mer lookups/s", "cores": threads, "kind": "port",
-            "sample": "%d %s (%d lookups) in %.1f s, cycling the timed batch of %d; oracle = sorted "
+            "sample": "%d %s (%d lookups) in %.1f s, cycling one timed batch of %d; oracle = sorted "
                       "(key,id) array + binary search, not Badger" % (nqd, "reads" if kind == "reads" else "queries", lookups, dt, nq),
             "queries_per_s": nqd / dt}
 
@@ -84,39 +102,47 @@ def cpu_baseline(oix, queries, seconds=12.0, threads=None, kind="protein"):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--db-proteins", type=int, default=560000)
-    ap.add_argument("--workload", choices=["protein", "reads"], default="protein",
-                    help="protein = BASELINE configs[1] (default); reads = configs[2]: 150-nt reads, 6-frame path")
+    ap.add_argument("--db", choices=["sp", "zipf"], default="sp",
+                    help="sp = DB-SP of SURVEY 8d (default); zipf = the same size with Zipf-distributed shared motifs "
+                         "(postings lists of 1e4 and more): a reported secondary line, never the headline")
+    ap.add_argument("--workload", choices=["protein", "reads", "mix"], default="protein",
+                    help="protein = BASELINE configs[1] (default); reads = configs[2]: 150-nt reads, 6-frame path; "
+                         "mix = Q-mix of configs[4]: 100/150/250-nt reads + 5 %% long reads")
     ap.add_argument("--queries", type=int, default=0, help="sequences per batch (default 10000 proteins / 1000000 reads)")
+    ap.add_argument("--batches-per-step", type=int, default=0,
+                    help="batches pushed back to back in one step (default 200 protein batches / 3 read batches: ~25 ms)")
+    ap.add_argument("--distinct-batches", type=int, default=8,
+                    help="different pre-generated batches the steps rotate over (their bucket footprint exceeds the Infinity Cache)")
     ap.add_argument("--load-factor", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--check", type=int, default=50, help="queries checked against the oracle after timing")
     ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
-                    help="N>1: replicas = every rank holds the table and its own batch (default; the DB fits one GPU); "
+                    help="N>1: replicas = every rank holds the table and its own batches (default; the DB fits one GPU); "
                          "sharded = the table is split by hash prefix, all ranks search one common batch, partial hit "
-                         "lists are exchanged with one RCCL all-to-all and merged by the query's owner")
-    ap.add_argument("--time-every", type=int, default=8,
-                    help="bracket the kernels of every k-th timed step with HIP events (roofline.achieved is their average)")
+                         "lists are exchanged once per batch and merged by the query's owner")
+    ap.add_argument("--time-every", type=int, default=16,
+                    help="bracket the kernels of every k-th timed launch with HIP events (roofline.achieved is their average)")
     ap.add_argument("--post", type=int, default=0,
-                    help="1: every step also runs the device post-steps (sortMapByValue, SetBestStartCodon for reads, "
+                    help="1: every batch also runs the device post-steps (sortMapByValue, SetBestStartCodon for reads, "
                          "FilterResults: kaamer_topn_device with the reference's defaults)")
     ap.add_argument("--host-api", type=int, default=0,
                     help="1: also time the host-buffer calls once (PCIe-inclusive, informational, never `value`)")
-    ap.add_argument("--pipelined-probe", type=int, default=0,
-                    help="after the timed region also measure the same batches with three in flight (informational field)")
     ap.add_argument("--inflight", type=int, default=1,
-                    help="batches in flight: step i runs on workspace/stream i %% inflight, so the probe kernel of one batch "
-                         "(memory-request bound) overlaps the counting kernel of the previous one (LDS/latency bound)")
+                    help="batches in flight: batch i runs on workspace/stream i %% inflight")
     ap.add_argument("--compact", type=int, default=0,
                     help="1: finish every batch with the hit lists packed in query order (one more scan + copy pass); "
-                         "0 (default): each query's list stays where the counting kernel wrote it (offset + count per query)")
+                         "0 (default): each query's list stays where the search kernel wrote it (offset + count per query)")
     args = ap.parse_args()
 
+    nucl = args.workload in ("reads", "mix")
     if args.queries <= 0:
-        args.queries = 10000 if args.workload == "protein" else 1000000
+        args.queries = 1000000 if nucl else 10000
+    if args.batches_per_step <= 0:
+        args.batches_per_step = 3 if nucl else 200
     _tame_malloc()
     import numpy as np
     import torch
@@ -134,11 +160,11 @@ def main():
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
     torch.cuda.set_device(local_rank)
 
-    from kaamer_amd import api, workload
+    from kaamer_amd import abi, api, workload
 
     t0 = time.time()
-    db = workload.make_db(args.db_proteins)
-    log("DB: %d proteins, %d residues (%.1fs)" % (args.db_proteins, int(db[1][-1]), time.time() - t0))
+    db = workload.make_db(args.db_proteins) if args.db == "sp" else workload.make_db_zipf(args.db_proteins)
+    log("DB (%s): %d proteins, %d residues (%.1fs)" % (args.db, args.db_proteins, int(db[1][-1]), time.time() - t0))
     t0 = time.time()
     img = api.Image.from_proteins(packed=db, load_factor=args.load_factor,
                                   shard=rank if sharded_mode else 0, n_shards=world if sharded_mode else 1)
@@ -147,169 +173,186 @@ def main():
     t0 = time.time()
     ix = api.Index.from_image(img, local_rank)
     img.close()
-    log("index resident in HBM (%.2f GB) in %.1fs" % ((st["n_buckets"] * 64 + st["arena_words"] * 4) / 1e9, time.time() - t0))
+    table_bytes = st["n_buckets"] * 128 + st["arena_words"] * 4
+    log("index resident in HBM (%.2f GB) in %.1fs" % (table_bytes / 1e9, time.time() - t0))
 
-    # every rank searches its own batch (replicas): same generator, rank-specific seed
-    from kaamer_amd import abi
-    reads = args.workload == "reads"
-    if reads:
-        q = workload.make_reads(db, args.queries, seed=workload.SEED + 2 + 1000 * rank)
-    else:
-        q = workload.make_protein_queries(db, args.queries, seed=workload.SEED + 1 + (0 if sharded_mode else 1000 * rank))
-    qbuf, qoff = q
-    d_buf = torch.from_numpy(qbuf).cuda()
-    d_off = torch.from_numpy(qoff.view(np.int64)).cuda()
-    ws = api.Workspace(ix, len(qbuf), args.queries,
-                       seq_type=abi.READS if reads else abi.PROTEIN,
-                       max_hits=(64 << 20) if reads else 0, first_pos=1 if sharded_mode else 0,
-                       compact=bool(args.compact))
+    # ---- the batches: same generator, a different seed per batch (and per rank: replicas search their own batches)
+    n_distinct = max(1, args.distinct_batches)
+    seq_type = abi.READS if nucl else abi.PROTEIN
+    batches = []
+    for b in range(n_distinct):
+        seed = workload.SEED + 1 + 17 * b + (0 if sharded_mode else 1000 * rank)
+        if args.workload == "reads":
+            q = workload.make_reads(db, args.queries, seed=seed + 1)
+        elif args.workload == "mix":
+            q = workload.make_reads_mix(db, args.queries, seed=seed + 1)
+        else:
+            q = workload.make_protein_queries(db, args.queries, seed=seed)
+        batches.append(q)
+    d_bufs = [torch.from_numpy(q[0]).cuda() for q in batches]
+    d_offs = [torch.from_numpy(q[1].view(np.int64)).cuda() for q in batches]
+    max_bytes = max(len(q[0]) for q in batches)
+    ws_kw = dict(seq_type=seq_type, max_hits=(64 << 20) if nucl else 0, compact=bool(args.compact))
     stream = torch.cuda.current_stream().cuda_stream
-    if sharded_mode:
-        assert not reads, "sharded mode: protein workload only in this round"
-        from kaamer_amd import sharded
-        mws = api.Workspace(ix, len(qbuf), args.queries, first_pos=1, max_hits=16 << 20)
-        searcher = sharded.ShardedSearcher(ix, ws, mws, rank, world)
 
-        def step():
-            return searcher.step(d_buf, d_off, args.queries, len(qbuf), stream)
+    if sharded_mode:
+        from kaamer_amd import sharded
+        assert not nucl, "sharded mode: protein workload only until the exchange moves under the C ABI"
+        sws = api.Workspace(ix, max_bytes, args.queries, first_pos=1, **ws_kw)
+        mws = api.Workspace(ix, max_bytes, args.queries, first_pos=1, max_hits=16 << 20)
+        searcher = sharded.ShardedSearcher(ix, sws, mws, rank, world)
+
+        def launch(i):
+            b = i % n_distinct
+            return searcher.step(d_bufs[b], d_offs[b], args.queries, len(batches[b][0]), stream)[0]
+        wss, streams = [mws], [stream]
     else:
-        wss = [ws] + [api.Workspace(ix, len(qbuf), args.queries, seq_type=abi.READS if reads else abi.PROTEIN,
-                                    max_hits=(64 << 20) if reads else 0, compact=bool(args.compact))
-                      for _ in range(args.inflight - 1)]
+        wss = [api.Workspace(ix, max_bytes, args.queries, **ws_kw) for _ in range(args.inflight)]
         extra_streams = [torch.cuda.Stream() for _ in range(args.inflight - 1)]  # kept alive
         streams = [stream] + [x.cuda_stream for x in extra_streams]
-        step_no = [0]
 
-        def step():
-            i = step_no[0] % args.inflight
-            step_no[0] += 1
-            r = wss[i].search_device(d_buf.data_ptr(), d_off.data_ptr(), args.queries, len(qbuf), stream=streams[i])
+        def launch(i):
+            b, w = i % n_distinct, i % args.inflight
+            r = wss[w].search_device(d_bufs[b].data_ptr(), d_offs[b].data_ptr(), args.queries, len(batches[b][0]), stream=streams[w])
             if args.post:
-                wss[i].topn_device(0.05, 10, 10, best_start_codon=reads, stream=streams[i])
+                wss[w].topn_device(0.05, 10, 10, best_start_codon=nucl, stream=streams[w])
             return r
 
-    for _ in range(args.warmup):
-        step()
-    counters = (mws if sharded_mode else ws).finish(stream)  # also validates the batch (capacity / overflow)
-    if not sharded_mode:
-        for w_, s_ in zip(wss[1:], streams[1:]):
-            w_.finish(s_)
-    ws.set_timing(args.time_every)  # sampled: an event record idles the stream for a few microseconds
-    ws.reset_timers()
+    def finish_all():
+        c = None
+        for w_, s_ in zip(wss, streams):
+            c = w_.finish(s_)   # also validates the batch (capacity / overflow)
+        return c
+
+    # exact work counters of every distinct batch (counted by the kernels), one untimed pass each
+    per_batch = []
+    for b in range(n_distinct):
+        if sharded_mode:
+            per_batch.append(searcher.step(d_bufs[b], d_offs[b], args.queries, len(batches[b][0]), stream)[2])
+            mws.finish(stream)
+        else:
+            wss[0].search_device(d_bufs[b].data_ptr(), d_offs[b].data_ptr(), args.queries, len(batches[b][0]), stream=streams[0])
+            per_batch.append(wss[0].finish(streams[0]))
+    n_launch = 0
+    for _ in range(args.warmup * args.batches_per_step):
+        launch(n_launch)
+        n_launch += 1
+    finish_all()
+    wss[0].set_timing(args.time_every)  # sampled: an event record idles the stream for a few microseconds
+    wss[0].reset_timers()
 
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
+    first_timed = n_launch
     last = None
     for _ in range(args.steps):
-        last = step()
+        for _ in range(args.batches_per_step):
+            last = launch(n_launch)
+            n_launch += 1
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
-    if sharded_mode:
-        mws.finish(stream)
-        counters = step()[2]  # the local search's counters (one extra, untimed step)
-        mws.finish(stream)
-    else:
-        for w_, s_ in zip(wss[1:], streams[1:]):
-            w_.finish(s_)
-        counters = ws.finish(stream)
-    tm = ws.kernel_ms_sum()
+    last_batch = (n_launch - 1) % n_distinct
+    finish_all()
+    tm = wss[0].kernel_ms_sum()
     n_calls = max(tm["calls"], 1)
 
-    # informational, after the timed region and never `value`: the same batches with three in flight on
-    # three streams/workspaces (the next batch's probe kernel overlaps this batch's counting kernel)
-    pipelined = None
-    if not sharded_mode and world == 1 and args.inflight == 1 and args.pipelined_probe:
-        pw = [ws] + [api.Workspace(ix, len(qbuf), args.queries, seq_type=abi.READS if reads else abi.PROTEIN,
-                                   max_hits=(64 << 20) if reads else 0, compact=bool(args.compact)) for _ in range(2)]
-        pstr_keep = [torch.cuda.Stream() for _ in range(2)]
-        pstr = [stream] + [x.cuda_stream for x in pstr_keep]
-        ws.set_timing(0)
-        n_p = max(30, min(args.steps, 300)) if not reads else 9
-        for i in range(6):
-            pw[i % 3].search_device(d_buf.data_ptr(), d_off.data_ptr(), args.queries, len(qbuf), stream=pstr[i % 3])
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(n_p):
-            pw[i % 3].search_device(d_buf.data_ptr(), d_off.data_ptr(), args.queries, len(qbuf), stream=pstr[i % 3])
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        for w_, s_ in zip(pw, pstr):
-            w_.finish(s_)
-        pipelined = {"batches_in_flight": 3, "steps": n_p, "ms_per_step": dt / n_p * 1e3,
-                     "lookups_per_s": float(counters["n_lookup"]) * n_p / dt}
+    # work of the timed region = sum over the launches of their batch's exact counters
+    n_timed = n_launch - first_timed
+    times_run = [len(range((b - first_timed) % n_distinct, n_timed, n_distinct)) for b in range(n_distinct)]
+    keys = per_batch[0].keys()
+    tot = {k: sum(per_batch[b][k] * times_run[b] for b in range(n_distinct)) for k in keys}
+    avg = {k: tot[k] / n_timed for k in keys}   # per launch
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    lk = torch.tensor([float(counters["n_lookup"]), float(args.queries) / (world if sharded_mode else 1)],
+    lk = torch.tensor([float(tot["n_lookup"]), float(args.queries) * n_timed / (world if sharded_mode else 1)],
                       dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(lk, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
-    lookups_per_step = float(lk[0].item())
-    queries_per_step = float(lk[1].item())
+    lookups_total = float(lk[0].item())
+    queries_total = float(lk[1].item())
 
-    # ---- roofline of the dominant kernel (probe_kernel), HBM bound ------------------------------
-    # algorithmic bytes per launch (DESIGN.md "Measurement"), from exact kernel-side counters:
-    #   probe_kernel : 1 B per residue position + 1 bit per position (k-mer-start bitmap)
-    #                  + 64 B per bucket inspected + 4 B per position (the val it writes)
-    #   count kernels: 4 B per position (val read back) + 4 B per arena word that must be read
-    #                  (list header + ids) + 12 B per emitted hit (pid, kmatch, first_pos)
-    c = counters
-    n_pos = int(c["n_in"]) if reads else int(qoff[-1])  # residue positions kernel P walks (reads: ORF amino acids)
-    probe_bytes = n_pos + n_pos // 8 + 64 * c["n_probe"] + 4 * n_pos
-    count_bytes = 4 * n_pos + 4 * (c["n_lists"] + c["n_list_ids"]) + 12 * c["n_hits"]
-    probe_s = tm["probe_ms"] / n_calls / 1e3
-    count_s = tm["count_ms"] / n_calls / 1e3
-    achieved = probe_bytes / probe_s / 1e9 if probe_s > 0 else 0.0
-    # HBM traffic from the PMC counters is collected in separate rocprofv3 passes (profiles/); it is
-    # reported here only when this run is the workload those passes measured
+    # ---- roofline, HBM bound (DESIGN.md "Measurement"); per LAUNCH (= one batch), from exact kernel-side counters:
+    #   search_group_kernel (the dominant kernel: probe + count in one launch)
+    #       1 B per residue position + 128 B per bucket inspected (8 cells x 16 B: keys AND their short
+    #       postings lists) + 4 B per protein id read from the arena (lists of more than 6 ids)
+    #       + 28 B per query (descriptor 16 + table offset 8 + hit count 4) + 8 B per query written (list offset)
+    #       + 8 or 12 B per emitted hit (pid, Kmatch[, first position])
+    #   rest of the step: prep (8 B offsets + 40 B meta + 24 B descriptor/offset per query, 1 B per sequence end),
+    #       translation for nucleotide input (1 B per nucleotide read twice: COUNT + WRITE; ORF residues, starts
+    #       and 40 B of meta written per ORF), G tier (rare)
+    c = avg
+    hit_b = 12 if (nucl or sharded_mode) else 8
+    search_bytes = c["n_in"] + 128 * c["n_probe"] + 4 * c["n_list_ids"] + 36 * c["n_queries"] + hit_b * c["n_hits"]
+    if nucl:
+        nt = float(np.mean([len(q[0]) for q in batches]))
+        rest_bytes = 2 * nt + 48 * args.queries + c["n_in"] + 64 * c["n_queries"]
+    else:
+        rest_bytes = 9 * args.queries + 72 * c["n_queries"]
+    search_s = tm["probe_ms"] / n_calls / 1e3
+    tail_s = tm["count_ms"] / n_calls / 1e3
+    step_s = elapsed / n_timed  # per batch, wall clock of the timed region
+    # HBM traffic from the PMC counters is collected in separate rocprofv3 passes (profiles/); reported here only
+    # when this run is the workload those passes measured
     traffic = None
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_probe_kernel.json")))
-        if (pm["config"]["db_proteins"], pm["config"]["queries"], pm["config"]["workload"]) == \
-                (args.db_proteins, args.queries, args.workload):
-            traffic = pm["probe_kernel"]["traffic_bytes_per_launch"]
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+        for e in pm["runs"]:
+            if (e["db_proteins"], e["queries"], e["workload"], e["db"]) == (args.db_proteins, args.queries, args.workload, args.db):
+                traffic = e["search_group_kernel"]["traffic_bytes_per_launch"]
     except Exception:
         pass
-    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                "random_request_ceiling": {"G_requests_per_s": 51.0, "achieved_G_probes_per_s": c["n_probe"] / probe_s / 1e9 if probe_s > 0 else 0.0,
-                                           "source": "tools/random_read_bench.hip (profiles/r01_pmc_traffic_probe_kernel.json)"},
-                "kernel": "probe_kernel", "kernel_ms": probe_s * 1e3, "timed_launches": n_calls,
-                "algorithmic_bytes_per_launch": probe_bytes,
-                "bytes_per_lookup": probe_bytes / max(c["n_lookup"], 1),
-                "min_bytes_8B_slot": n_pos + n_pos // 8 + 8 * c["n_lookup"] + 4 * n_pos,
-                "count_kernels": {"ms": count_s * 1e3, "algorithmic_bytes": count_bytes,
-                                  "achieved_GBps": count_bytes / count_s / 1e9 if count_s > 0 else 0.0},
-                "whole_batch": {"ms": tm["total_ms"] / n_calls,
-                                "achieved_GBps": (probe_bytes + count_bytes) / (tm["total_ms"] / n_calls / 1e3) / 1e9
-                                if tm["total_ms"] > 0 else 0.0}}
+    whole_bytes = search_bytes + rest_bytes
+    roofline = {
+        "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+        # the WHOLE step: all algorithmic bytes of a batch / wall time per batch of the timed region
+        "achieved": whole_bytes / step_s / 1e9, "frac": whole_bytes / step_s / 1e9 / HBM_PEAK_GBPS,
+        "traffic": traffic,
+        "scope": "whole batch (prep + search kernel + G tier), wall clock of the timed region",
+        "algorithmic_bytes_per_batch": whole_bytes,
+        "bytes_per_lookup": whole_bytes / max(c["n_lookup"], 1),
+        "dominant_kernel": {
+            "name": "search_group_kernel (probe + count)", "ms": search_s * 1e3, "timed_launches": n_calls,
+            "algorithmic_bytes_per_launch": search_bytes,
+            "achieved": search_bytes / search_s / 1e9 if search_s > 0 else 0.0,
+            "frac": search_bytes / search_s / 1e9 / HBM_PEAK_GBPS if search_s > 0 else 0.0,
+            "share_of_batch_time": search_s / step_s if step_s > 0 else 0.0,
+            "G_random_requests_per_s": (c["n_probe"] + c["n_lists"]) / search_s / 1e9 if search_s > 0 else 0.0,
+            "random_request_ceiling_G_per_s": 53.0,  # tools/random_read_bench.hip: 16..128-byte records alike
+        },
+        "other_kernels_ms": tail_s * 1e3,
+        "hip_event_batch_ms": tm["total_ms"] / n_calls,
+        "min_bytes_8B_slot": c["n_in"] + 8 * c["n_lookup"] + 4 * c["n_post"] + hit_b * c["n_hits"],
+    }
 
+    cfg_workload = {"protein": "configs[1]: batches of %d protein queries per GPU vs ",
+                    "reads": "configs[2]: 6-frame path, batches of %d synthetic 150-nt reads per GPU vs ",
+                    "mix": "configs[4] data (Q-mix: 100/150/250-nt + 5%% long reads), batches of %d reads per GPU vs "}[args.workload] % args.queries
     out = {
-        "metric": "k-mer lookups/sec", "value": lookups_per_step * args.steps / elapsed,
+        "metric": "k-mer lookups/sec", "value": lookups_total / elapsed,
         "unit": "k-mer lookups/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if sharded_mode else "weak",
         "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-        "config": {"workload": ("configs[2]: 6-frame path, %d synthetic 150-nt reads per GPU per step vs " if reads else
-                                "configs[1]: %d protein queries per GPU per step vs ") % args.queries +
-                               "Swiss-Prot-sized synthetic DB (%d proteins, %d residues, %d distinct 7-mers) resident in HBM"
-                               % (args.db_proteins, int(db[1][-1]), st["n_keys"]),
-                   "parallelism": ("hash-prefix shards x%d, one all-to-all of partial hit lists per batch" % world) if sharded_mode
+        "config": {"workload": cfg_workload + ("Swiss-Prot-sized synthetic DB" if args.db == "sp" else "Zipf-motif synthetic DB") +
+                               " (%d proteins, %d residues, %d distinct 7-mers, longest postings list %d) resident in HBM"
+                               % (args.db_proteins, int(db[1][-1]), st["n_keys"], st["max_list"]),
+                   "batches_per_step": args.batches_per_step, "distinct_batches": n_distinct,
+                   "ms_per_batch": step_s * 1e3,
+                   "parallelism": ("hash-prefix shards x%d, one exchange of partial hit lists per batch" % world) if sharded_mode
                                   else ("replicas x%d (no collective)" % world if world > 1 else "single GPU"),
                    "result": "device-resident per-query hit lists (offset, count, protein ids, Kmatch)" +
                              (", packed in query order" if args.compact else ""),
                    "batches_in_flight": args.inflight, "device_post_steps": bool(args.post),
-                   "seed": workload.SEED},
-        "query_seqs_per_s": queries_per_step * args.steps / elapsed,
-        "counters_per_step_rank0": c,
+                   "table_bytes": table_bytes, "seed": workload.SEED},
+        "query_seqs_per_s": queries_total / elapsed,
+        "counters_per_batch_rank0": {k: round(v, 1) for k, v in c.items()},
         "roofline": roofline,
     }
-    if pipelined:
-        out["pipelined_informational"] = pipelined
 
     if rank == 0:
         want_cpu = not args.no_cpu_baseline and world == 1 and not sharded_mode
@@ -320,10 +363,12 @@ def main():
             t0 = time.time()
             oix = O.Index.from_proteins(None, packed=db)
             log("oracle index built in %.1fs" % (time.time() - t0))
+            q = batches[last_batch]
             if args.check:
-                # the device-resident result of the last TIMED step, read back as it lies in HBM
+                # the device-resident result of the last TIMED batch, read back as it lies in HBM
                 from kaamer_amd.sharded import dev_tensor
-                sub = workload.unpack(q)[:args.check]
+                sub = workload.unpack((q[0], q[1][:args.check + 1]))
+                counters = per_batch[last_batch]
                 nq_dev = int(counters["n_queries"])
                 cap = int(last.hit_capacity)
                 r_off = dev_tensor(last.d_hit_off, nq_dev, torch.int64).cpu().numpy()
@@ -331,42 +376,38 @@ def main():
                 r_pid = dev_tensor(last.d_hit_pid, cap, torch.int32).cpu().numpy().view(np.uint32)
                 r_km = dev_tensor(last.d_hit_kmatch, cap, torch.int32).cpu().numpy()
 
-                class res:
-                    n_queries = nq_dev
-
-                    @staticmethod
-                    def hits(i):
-                        a = int(r_off[i])
-                        return dict(zip(r_pid[a:a + int(r_cnt[i])].tolist(), r_km[a:a + int(r_cnt[i])].tolist()))
-                if reads:
+                def hits(i):
+                    a = int(r_off[i])
+                    return dict(zip(r_pid[a:a + int(r_cnt[i])].tolist(), r_km[a:a + int(r_cnt[i])].tolist()))
+                if nucl:
                     qi = 0
                     for s in sub:
                         for o in O.get_orfs(s):
                             pid, km, _ = oix.search(o["seq"])
-                            assert res.hits(qi) == dict(zip(pid.tolist(), km.tolist())), "bench: ORF %d differs from the oracle" % qi
+                            assert hits(qi) == dict(zip(pid.tolist(), km.tolist())), "bench: ORF %d differs from the oracle" % qi
                             qi += 1
-                    assert qi <= res.n_queries
+                    assert qi <= nq_dev
                 else:
                     for i, s in enumerate(sub):
                         exp = {}
                         if O.size_in_kmer(s) >= 7:
                             pid, km, _ = oix.search(s)
                             exp = dict(zip(pid.tolist(), km.tolist()))
-                        assert res.hits(i) == exp, "bench: query %d differs from the oracle" % i
+                        assert hits(i) == exp, "bench: query %d differs from the oracle" % i
                 out["parity_checked_queries"] = len(sub)
-                log("parity: %d queries of the timed batch bit-exact vs oracle" % len(sub))
+                log("parity: %d queries of the last timed batch bit-exact vs oracle" % len(sub))
             if args.host_api:
                 hb = {}
-                for name, fn in (("search_batch_top", lambda: ix.search_top(packed=q, seq_type=abi.READS if reads else abi.PROTEIN)),
-                                 ("search_batch", lambda: ix.search(packed=q, seq_type=abi.READS if reads else abi.PROTEIN))):
+                for name, fn in (("search_batch_top", lambda: ix.search_top(packed=q, seq_type=seq_type)),
+                                 ("search_batch", lambda: ix.search(packed=q, seq_type=seq_type))):
                     fn()
                     t0 = time.perf_counter()
                     fn()
-                    hb[name] = {"ms": (time.perf_counter() - t0) * 1e3,
-                                "lookups_per_s": c["n_lookup"] / (time.perf_counter() - t0)}
+                    dt = time.perf_counter() - t0
+                    hb[name] = {"ms": dt * 1e3, "lookups_per_s": per_batch[last_batch]["n_lookup"] / dt}
                 out["host_buffer_calls_pcie_inclusive"] = hb
             if want_cpu:
-                out["cpu_baseline"] = cpu_baseline(oix, q, seconds=args.cpu_seconds, kind="reads" if reads else "protein")
+                out["cpu_baseline"] = cpu_baseline(oix, q, seconds=args.cpu_seconds, kind="reads" if nucl else "protein")
         print(json.dumps(out), flush=True)
     if world > 1 or sharded_mode:
         dist.barrier()

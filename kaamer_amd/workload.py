@@ -168,6 +168,78 @@ def make_reads(db, n_reads, read_len=150, seed=SEED + 2, db_frac=0.9, subst=0.01
     return np.ascontiguousarray(reads).reshape(-1), _offsets(lens)
 
 
+def make_reads_mix(db, n_reads, seed=SEED + 3, db_frac=0.9, subst=0.01, n_rate=0.001):
+    """Q-mix of SURVEY 8d (BASELINE configs[4]): read lengths 100 / 150 / 250 nt (30 / 50 / 15 %) plus 5 % long
+    reads (log-normal, median 3 kb, sigma 0.5, clip 500..20000).  db_frac of the reads carry a back-translated
+    window of a DB protein (as long as the read and the protein allow, random strand and offset inside the
+    read); the rest, and everything around the window, is uniform random ACGT.  -> (buf, offsets)."""
+    buf, offs = db
+    n_db = len(offs) - 1
+    rng = np.random.default_rng(seed)
+    u = rng.random(n_reads)
+    lens = np.where(u < 0.30, 100, np.where(u < 0.80, 150, 250)).astype(np.int64)
+    is_long = u >= 0.95
+    ll = np.clip(np.rint(np.exp(rng.normal(np.log(3000.0), 0.5, n_reads))), 500, 20000).astype(np.int64)
+    lens[is_long] = ll[is_long]
+    roffs = _offsets(lens)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    out = acgt[rng.integers(0, 4, int(roffs[-1]))]
+    from_db = np.flatnonzero(rng.random(n_reads) < db_frac)
+    if len(from_db):
+        db_len = (offs[1:] - offs[:-1]).astype(np.int64)
+        src = rng.integers(0, n_db, len(from_db))
+        aa_n = np.minimum(lens[from_db] // 3, db_len[src])                        # residues back-translated
+        start = (rng.random(len(src)) * (db_len[src] - aa_n + 1)).astype(np.int64)
+        room = lens[from_db] - 3 * aa_n
+        at = (rng.random(len(src)) * (room + 1)).astype(np.int64)                 # where the window sits in the read
+        aa = buf[_gather_index(offs[:-1][src].astype(np.int64) + start, aa_n)]
+        pick = (rng.random(len(aa)) * _CODON_COUNT[aa]).astype(np.int64)
+        nt = _CODONS[aa, pick].reshape(-1)                                       # lower-case, 3 per residue
+        nt = np.where((nt >= 97) & (nt <= 122), nt - 32, nt).astype(np.uint8)
+        sub = rng.random(len(nt), dtype=np.float32) < subst
+        nt[sub] = acgt[rng.integers(0, 4, int(sub.sum()))]
+        # minus strand: reverse-complement the window in place (segment-wise reversal through an index)
+        seg_len = 3 * aa_n
+        seg_off = np.zeros(len(seg_len), dtype=np.int64)
+        seg_off[1:] = np.cumsum(seg_len[:-1])
+        minus = rng.random(len(src)) < 0.5
+        within = np.arange(len(nt), dtype=np.int64) - np.repeat(seg_off, seg_len)
+        rev_idx = np.repeat(seg_off + seg_len - 1, seg_len) - within
+        is_minus = np.repeat(minus, seg_len)
+        nt = np.where(is_minus, _COMP[nt[rev_idx]], nt)
+        out[_gather_index(roffs[:-1][from_db].astype(np.int64) + at, seg_len)] = nt
+    nmask = rng.random(len(out), dtype=np.float32) < n_rate
+    out[nmask] = ord("N")
+    return np.ascontiguousarray(out), roffs
+
+
+def make_db_zipf(n_proteins, seed=SEED + 7, n_motifs=100000, zipf_a=0.8, per_residues=60):
+    """A DB of the size and length distribution of DB-SP whose shared content follows a power law, like the
+    domain families of a real protein database: proteins are random background with motifs (15..40 residues)
+    pasted in, one per `per_residues` residues, the motif drawn with P(rank r) ~ r^-zipf_a from a library of
+    `n_motifs`.  The most frequent motifs occur in 1e4..1e5 proteins, so their 7-mers have postings lists of
+    that length (the stress case for the postings expansion and the counting tables)."""
+    rng = np.random.default_rng(seed)
+    lens = _lengths(rng, n_proteins)
+    offs = _offsets(lens)
+    buf = _residues(rng, int(offs[-1]))
+    mlen = rng.integers(15, 41, n_motifs).astype(np.int64)
+    moff = _offsets(mlen)
+    mbuf = _residues(rng, int(moff[-1]))
+    w = np.arange(1, n_motifs + 1, dtype=np.float64) ** (-zipf_a)
+    cdf = np.cumsum(w / w.sum())
+    n_ins = np.maximum(lens // per_residues, 1)
+    total = int(n_ins.sum())
+    motif = np.minimum(np.searchsorted(cdf, rng.random(total), side="right"), n_motifs - 1)
+    prot = np.repeat(np.arange(n_proteins), n_ins)
+    ml = mlen[motif]
+    ok = ml <= lens[prot]
+    motif, prot, ml = motif[ok], prot[ok], ml[ok]
+    at = (rng.random(len(prot)) * (lens[prot] - ml + 1)).astype(np.int64)
+    buf[_gather_index(offs[:-1][prot].astype(np.int64) + at, ml)] = mbuf[_gather_index(moff[:-1][motif].astype(np.int64), ml)]
+    return buf, offs
+
+
 def unpack(packed):
     buf, offs = packed
     return [bytes(buf[int(offs[i]):int(offs[i + 1])]) for i in range(len(offs) - 1)]
