@@ -93,10 +93,12 @@ KH_HD uint32_t kh_residue_code(uint8_t c)
     default: return KH_CODE_UNKNOWN;
     }
 }
+// (written as selects: the kernels evaluate this for every residue position, and exec-mask branches cost more than the arithmetic)
 KH_HD uint32_t kh_pair(uint32_t a, uint32_t b)
 {
-    if (a >= 21u) return 0u;
-    return b < 21u ? (22u + 21u * a + b) : (b == KH_CODE_DOT ? a : 0u);
+    const uint32_t both = 22u + 21u * a + b;
+    const uint32_t r = b < 21u ? both : (b == KH_CODE_DOT ? a : 0u);
+    return a < 21u ? r : 0u;
 }
 KH_HD uint32_t kh_key_from_codes(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t c4,
                                  uint32_t c5, uint32_t c6)

@@ -15,7 +15,7 @@
 //   probe_kernel          the dominant kernel: flat over residue positions; sliding 7-mer
 //                         encode (k_store.go:91-117, search_protein.go:94-98) and bucket
 //                         probe (replaces KmerStore.Get, search.go:421) -> vals[pos]
-//   search_group_kernel    (count_group.hip.inc) postings expansion + Counter increments
+//   count_group_kernel    (count_group.hip.inc) postings expansion + Counter increments
 //                         (search.go:427-436, 442-452) in LDS hash tables, one 8-wave
 //                         workgroup per query group; a wave per query packs its table into
 //                         the query's hit list at E[q]
@@ -39,6 +39,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "kaamer_internal.h"
@@ -170,42 +171,6 @@ __device__ __forceinline__ uint32_t table_home_bucket(const TableRef &t, uint32_
     return __umulhi(rest, (uint32_t)t.n_buckets);
 }
 
-// The 7-mer that starts at byte `a` of the residue buffer, from the three aligned words that cover it
-// (d2 is only looked at when the window needs it), encoded like EncodeKmer (k_store.go:91-117).
-// `lut` maps a byte to its residue code (kh_residue_code) and lives in LDS.
-__device__ __forceinline__ uint32_t key_from_words(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t sh, const uint8_t *lut)
-{
-    const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh);  // residues 0..3
-    const uint32_t hi = __builtin_amdgcn_alignbyte(d2, d1, sh);  // residues 4..6 (+1)
-    return kh_key_from_codes(lut[lo & 0xFFu], lut[(lo >> 8) & 0xFFu], lut[(lo >> 16) & 0xFFu], lut[lo >> 24], lut[hi & 0xFFu],
-                             lut[(hi >> 8) & 0xFFu], lut[(hi >> 16) & 0xFFu]);
-}
-// the three words: residues a .. a+6 lie in bytes [a & ~3, (a & ~3) + 12); the third word is read
-// only when the window reaches into it, so nothing past the word that holds residue a+6 is touched.
-// `words` is the residue buffer rounded down to a 4-byte boundary and `a` counts from there (the
-// pointer must stay derived from the kernel argument: through an integer it would become a FLAT
-// pointer, and FLAT loads force vmcnt(0) waits on everything in flight).
-struct ResidueWords {
-    const uint32_t *words;
-    uint32_t mis;  // bytes between `words` and the first residue (0..3)
-};
-__device__ __forceinline__ ResidueWords residue_words(const uint8_t *residues)
-{
-    ResidueWords r;
-    r.mis = (uint32_t)(reinterpret_cast<uintptr_t>(residues) & 3u);
-    r.words = reinterpret_cast<const uint32_t *>(residues - r.mis);
-    return r;
-}
-__device__ __forceinline__ void load_kmer_words(const ResidueWords &rw, uint64_t a, uint32_t &d0, uint32_t &d1, uint32_t &d2, uint32_t &sh)
-{
-    a += rw.mis;
-    const uint32_t *w = rw.words + (a >> 2);
-    sh = (uint32_t)a & 3u;
-    d0 = w[0];
-    d1 = w[1];
-    d2 = w[sh >= 2u ? 2 : 1];
-}
-
 // One lane looks a key up on its own (rare paths: the key's home bucket is full and does not hold it;
 // the G tier).  Returns the number of ids (0 = absent); c0 = the matching cell, c1 = its continuation.
 struct LaneHit {
@@ -219,19 +184,6 @@ __device__ __forceinline__ uint32_t cell_count(const uint4 &c0, const uint4 &c1)
     if (c0.w & KH_CONT_BIT) n += 1u + (c1.z != KH_NO_ID ? 1u : 0u) + (c1.w != KH_NO_ID ? 1u : 0u);
     return n;
 }
-// id t (t < cnt) of a hit
-__device__ __forceinline__ uint32_t hit_id(const TableRef &tab, const LaneHit &h, uint32_t t)
-{
-    if (h.c0.y & KH_ARENA_BIT) return t == 0u ? h.c0.w : tab.arena[(uint64_t)(h.c0.y & ~KH_ARENA_BIT) * 4 + (t - 1u)];
-    switch (t) {
-    case 0: return h.c0.y;
-    case 1: return h.c0.z;
-    case 2: return h.c0.w & ~KH_CONT_BIT;
-    case 3: return h.c1.y;
-    case 4: return h.c1.z;
-    default: return h.c1.w;
-    }
-}
 __device__ __forceinline__ LaneHit lane_lookup(const TableRef &tab, uint32_t key, uint32_t bucket, uint32_t &n_probe)
 {
     LaneHit h;
@@ -240,16 +192,217 @@ __device__ __forceinline__ LaneHit lane_lookup(const TableRef &tab, uint32_t key
     for (uint64_t tries = 0; tries < tab.n_buckets; tries++) {
         n_probe++;
         const uint4 *cells = tab.cells + (uint64_t)bucket * KH_CELLS_PER_BUCKET;
-        uint4 c = cells[0];
-        for (int s = 0; s < KH_CELLS_PER_BUCKET; s++) {  // one cell at a time: few registers, the path is rare
-            const uint4 nx = s + 1 < KH_CELLS_PER_BUCKET ? cells[s + 1] : make_uint4(KH_EMPTY_KEY, 0, 0, 0);
-            if (c.x == key) { h.c0 = c; h.c1 = nx; h.cnt = cell_count(c, nx); return h; }
-            if (c.x == KH_EMPTY_KEY) return h;  // a bucket with a free cell ends the probe sequence
-            c = nx;
-        }
+        // the whole bucket in one go: eight independent loads, one memory round trip
+        const uint4 c0 = cells[0], c1 = cells[1], c2 = cells[2], c3 = cells[3], c4 = cells[4], c5 = cells[5], c6 = cells[6], c7 = cells[7];
+#define KH_TRY(a, b) if (a.x == key) { h.c0 = a; h.c1 = b; h.cnt = cell_count(a, b); return h; }
+        KH_TRY(c0, c1) KH_TRY(c1, c2) KH_TRY(c2, c3) KH_TRY(c3, c4) KH_TRY(c4, c5) KH_TRY(c5, c6) KH_TRY(c6, c7)
+#undef KH_TRY
+        if (c7.x == key) { h.c0 = c7; h.cnt = cell_count(c7, h.c1); return h; }
+        if (c7.x == KH_EMPTY_KEY) return h;  // a bucket with a free cell ends the probe sequence
         bucket = bucket + 1u == (uint32_t)tab.n_buckets ? 0u : bucket + 1u;
     }
     return h;
+}
+
+// ====================================================================================
+// Kernel P — flat probe over residue positions
+// ====================================================================================
+// Position i of the residue buffer is a k-mer start iff bit (i & 63) of invalid[i >> 6] is clear
+// (prep sets the tail of every query and whole queries that are too short).  One wave handles 64
+// consecutive positions: residue codes are staged in LDS, each lane encodes its 7-mer
+// (k_store.go:91-117 in closed form), then the wave reads the 64 home buckets, TWO lanes per
+// 128-byte bucket, four 16-byte cells each (lane s of the pair: cells s, s+2, s+4, s+6), 32
+// buckets per round, two rounds (tools/bucket_read_bench.hip: 2, 4 or 8 lanes per bucket reach the
+// same request rate, one lane per bucket a quarter of it; per-round work costs instructions).  The
+// lane whose cell matches writes the position's RECORD for the counting kernel:
+//     rec[i]  = {epoch, w1, w2, w3}  the matching cell's list words (kaamer_layout.h); the batch's tag in the
+//                                    first word: a position whose record carries another tag is absent, so the
+//                                    kernel writes nothing for the lookups that find nothing
+//     rec2[i] = the continuation cell (ids 3..5), written by the other lane of the pair (only then)
+// so the counting kernel reads everything it needs with two coalesced 16-byte loads per position: the
+// random requests of a lookup (KmerStore.Get + KCombStore.Get, search.go:421-429) all happen here,
+// one per lookup, flat over the batch whatever the query lengths are.
+struct ProbeParams {
+    TableRef tab;
+    const uint8_t *residues;
+    unsigned long long *invalid;        // one bit per position, set = not a k-mer start; self-cleaning
+    const unsigned long long *d_n_pos;  // device scalar: number of residue positions
+    uint4 *rec, *rec2;                  // one each per position
+    uint32_t epoch;                     // tag of this batch's records (never 0)
+    unsigned long long *counters;
+};
+
+#define P_WAVES 4
+#define P_RING 128u  /* deferred lookups per wave (a power of two): fewer than 64 waiting + the 64 of a window */
+
+// c ? a : b on VALUES.  (`c ? x.y : z.y` on lvalues is an lvalue: clang selects between the two ADDRESSES and loads
+// once, which pins a register array in scratch memory.)
+__device__ __forceinline__ uint32_t sel(bool c, uint32_t a, uint32_t b) { return c ? a : b; }
+
+#define KH_NO_KEY 0xFFFFFFFDu  /* "no lookup for this position": equals no cell key (valid keys, 0xFFFFFFFF empty, 0xFFFFFFFE continuation) */
+
+__global__ __launch_bounds__(64 * P_WAVES, 6) void probe_kernel(ProbeParams p)
+{
+    __shared__ uint8_t s_lut[256];
+    __shared__ uint8_t s_stage[P_WAVES][80];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));  // wave-uniform: window bases stay scalar
+    const uint32_t pair = lane >> 1, sub = lane & 1u;
+    const unsigned long long n_pos = *p.d_n_pos;
+    const unsigned long long n_win = (n_pos + 63) >> 6;
+    for (uint32_t i = tid; i < 256; i += 64 * P_WAVES) s_lut[i] = (uint8_t)kh_residue_code((uint8_t)i);
+    __syncthreads();  // the only workgroup barrier: the waves run independently from here on
+    uint32_t c_lookup = 0, c_probe = 0, c_found = 0;
+    uint8_t *stage = s_stage[wv];
+    const uint32_t n_buckets = (uint32_t)p.tab.n_buckets;
+    // Lookups whose home bucket is full and does not hold the key (a few per cent) go on in the NEXT bucket.  Waiting for
+    // that second request inside the window would stall the whole wave in six windows out of seven, so such lookups are
+    // put on a ring in LDS (key, position) and looked up later, 64 at a time, as a window of their own (STEP 1).
+    __shared__ uint32_t s_ring[P_WAVES][2][P_RING];
+    uint32_t *const ring_key = s_ring[wv][0], *const ring_pos = s_ring[wv][1];
+    uint32_t ring_head = 0, ring_n = 0;  // wave-uniform
+
+    // One window: `key` = the lane's key (KH_NO_KEY: none), its record at rec[base + off]; STEP = buckets past the home
+    // bucket.  Issue and consume are separate so that the next window's prefetch loads can be issued in between: every
+    // load of the loop is unconditional and in a fixed order, and the compiler's vmcnt(N) waits then count exactly.
+    struct Buckets { uint4 ld[2][4]; uint32_t rk[2], ro[2]; };
+    auto issue_window = [&](auto step_tag, uint32_t key, uint32_t off, Buckets &q) {
+        constexpr uint32_t STEP = decltype(step_tag)::value;
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            q.rk[r] = __shfl(key, 32 * r + (int)pair, 64);  // round r serves the keys of lanes 32r .. 32r+31
+            q.ro[r] = STEP == 0u ? 32u * (uint32_t)r + pair : __shfl(off, 32 * r + (int)pair, 64);
+            uint32_t bucket = 0u;
+            if (q.rk[r] != KH_NO_KEY) {
+                bucket = table_home_bucket(p.tab, q.rk[r]) + STEP;
+                if (STEP != 0u && bucket >= n_buckets) bucket -= n_buckets;
+            }
+            const uint4 *src = p.tab.cells + (uint64_t)bucket * KH_CELLS_PER_BUCKET + sub;
+#pragma unroll
+            for (int i = 0; i < 4; i++) q.ld[r][i] = load_cell(src + 2 * i, p.tab.nontemporal);
+        }
+        c_probe += key != KH_NO_KEY ? 1u : 0u;
+    };
+    auto consume_window = [&](auto step_tag, unsigned long long base, const Buckets &q) {
+        constexpr uint32_t STEP = decltype(step_tag)::value;
+        uint4 *const recw = p.rec + base, *const rec2w = p.rec2 + base;  // scalar bases, 32-bit lane offsets
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const uint32_t rk = q.rk[r], ro = q.ro[r];
+            const uint4 l0 = q.ld[r][0], l1 = q.ld[r][1], l2 = q.ld[r][2], l3 = q.ld[r][3];
+            // my matching cell, if any (a key is in at most one cell); selects on values, constant indices only
+            const bool m0 = l0.x == rk, m1 = l1.x == rk, m2 = l2.x == rk, m3 = l3.x == rk;
+            const bool m = m0 || m1 || m2 || m3;
+            const uint32_t mi = m0 ? 0u : m1 ? 1u : m2 ? 2u : m3 ? 3u : 4u;
+            // the other lane of the pair: did it match, and in which of its cells (quad_perm [1,0,3,2])
+            const uint32_t pmi = (uint32_t)__builtin_amdgcn_update_dpp(4, (int)mi, 0xB1, 0xf, 0xf, false);
+            if (m) {
+                recw[ro] = make_uint4(p.epoch, sel(m0, l0.y, sel(m1, l1.y, sel(m2, l2.y, l3.y))), sel(m0, l0.z, sel(m1, l1.z, sel(m2, l2.z, l3.z))),
+                                      sel(m0, l0.w, sel(m1, l1.w, sel(m2, l2.w, l3.w))));
+                c_found++;
+            }
+            // the cell after the partner's matching cell is mine: partner cell (1-s) + 2 pmi -> my piece pmi + (1-s)
+            const uint32_t k = pmi + 1u - sub;
+            const bool k0 = k == 0u, k1 = k == 1u, k2 = k == 2u;
+            const uint32_t cx = sel(k0, l0.x, sel(k1, l1.x, sel(k2, l2.x, l3.x)));
+            if (k < 4u && cx == KH_CONT_KEY && pmi < 4u)
+                rec2w[ro] = make_uint4(cx, sel(k0, l0.y, sel(k1, l1.y, sel(k2, l2.y, l3.y))), sel(k0, l0.z, sel(k1, l1.z, sel(k2, l2.z, l3.z))),
+                                       sel(k0, l0.w, sel(k1, l1.w, sel(k2, l2.w, l3.w))));
+            // the key is in neither half of this bucket, and the bucket has no free cell (its last cell, held by the odd
+            // lane, is in use): the lookup goes on
+            const bool wk = sub == 1u && !m && pmi >= 4u && l3.x != KH_EMPTY_KEY && rk != KH_NO_KEY;
+            const unsigned long long W = __ballot(wk);
+            if (W) {  // wave-uniform
+                if (STEP == 0u) {
+                    if (wk) {
+                        const uint32_t slot = (ring_head + ring_n + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(W >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)W, 0u))) & (P_RING - 1u);
+                        ring_key[slot] = rk;
+                        ring_pos[slot] = (uint32_t)base + ro;  // positions fit 32 bits (checked on the host)
+                    }
+                    ring_n += (uint32_t)__popcll(W);
+                } else if (wk) {  // full again (a fraction of a per cent of those): this lane walks on alone
+                    uint32_t bk = table_home_bucket(p.tab, rk) + STEP + 1u;
+                    if (bk >= n_buckets) bk -= n_buckets;
+                    const LaneHit h = lane_lookup(p.tab, rk, bk, c_probe);
+                    if (h.cnt != 0u) {
+                        recw[ro] = make_uint4(p.epoch, h.c0.y, h.c0.z, h.c0.w);
+                        if (!(h.c0.y & KH_ARENA_BIT) && (h.c0.w & KH_CONT_BIT)) rec2w[ro] = h.c1;
+                        c_found++;
+                    }
+                }
+            }
+        }
+    };
+    // up to 64 deferred lookups from the ring, one bucket further
+    auto drain_ring = [&]() {
+        const uint32_t n = ring_n < 64u ? ring_n : 64u;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t key = KH_NO_KEY, off = 0u;
+        if (lane < n) { key = ring_key[(ring_head + lane) & (P_RING - 1u)]; off = ring_pos[(ring_head + lane) & (P_RING - 1u)]; }
+        ring_head = (ring_head + n) & (P_RING - 1u);
+        ring_n -= n;
+        Buckets q;
+        issue_window(std::integral_constant<uint32_t, 1u>(), key, off, q);
+        consume_window(std::integral_constant<uint32_t, 1u>(), 0ull, q);
+    };
+
+    const unsigned long long stride = (unsigned long long)gridDim.x * P_WAVES;
+    unsigned long long w = (unsigned long long)blockIdx.x * P_WAVES + wv;
+    // software pipeline: the bitmap word and the residues of the NEXT window are loaded behind the bucket loads of the
+    // current one.  Windows and reads past the end are clamped (the positions involved are marked invalid or unused).
+    unsigned long long mask = 0;
+    uint32_t ra = 0, rb = 0;
+    auto fetch = [&](unsigned long long win, unsigned long long &m, uint32_t &a, uint32_t &b) {
+        const unsigned long long wc = win < n_win ? win : n_win - 1;
+        m = p.invalid[wc];
+        const unsigned long long i0 = (wc << 6) + lane, last = n_pos - 1;
+        a = p.residues[i0 < last ? i0 : last];
+        b = p.residues[i0 + 64 < last ? i0 + 64 : last];  // lanes 0..5 hold the halo
+    };
+    if (w < n_win) fetch(w, mask, ra, rb);
+
+    for (; w < n_win; w += stride) {
+        const unsigned long long base = w << 6;
+        const unsigned long long valid = ~mask;
+        if (lane == 0) p.invalid[w] = 0ull;  // leave the bitmap clean for the next batch
+        stage[lane] = s_lut[ra];
+        if (lane < 6) stage[64 + lane] = s_lut[rb];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint8_t *st = stage + lane;
+        uint32_t key = kh_key_from_codes(st[0], st[1], st[2], st[3], st[4], st[5], st[6]);
+        // not a k-mer start, or (sharded index) a key another device owns: no lookup, the position reads as absent
+        const bool own = p.tab.n_shards <= 1 || kh_shard_of(key, p.tab.n_shards) == p.tab.shard;
+        key = (((valid >> lane) & 1ull) && own) ? key : KH_NO_KEY;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        c_lookup += key != KH_NO_KEY ? 1u : 0u;
+        Buckets q;
+        issue_window(std::integral_constant<uint32_t, 0u>(), key, 0u, q);
+        fetch(w + stride, mask, ra, rb);      // lands while the buckets are fetched and consumed
+        consume_window(std::integral_constant<uint32_t, 0u>(), base, q);
+        if (ring_n >= 64u) drain_ring();
+    }
+    while (ring_n) drain_ring();
+    const uint32_t t_lookup = wave_total(c_lookup), t_probe = wave_total(c_probe), t_found = wave_total(c_found);
+    if (lane == 0) {
+        const uint32_t rep = blockIdx.x * P_WAVES + wv;
+        add_counter(p.counters, rep, CTR_LOOKUP, t_lookup);
+        add_counter(p.counters, rep, CTR_PROBE, t_probe);
+        add_counter(p.counters, rep, CTR_FOUND, t_found);
+    }
+}
+
+// a position's record -> number of ids (0 = absent) and whether the list lives in the arena
+__device__ __forceinline__ uint32_t rec_count(uint32_t epoch, const uint4 &h, const uint4 &c)
+{
+    // selects, not branches (evaluated for every position)
+    const bool arena = (h.y & KH_ARENA_BIT) != 0u, cont = (h.w & KH_CONT_BIT) != 0u;
+    const uint32_t head = 1u + (h.z != KH_NO_ID ? 1u : 0u) + ((h.w & ~KH_CONT_BIT) != KH_NO_ID ? 1u : 0u);
+    const uint32_t tail = 1u + (c.z != KH_NO_ID ? 1u : 0u) + (c.w != KH_NO_ID ? 1u : 0u);
+    const uint32_t n = arena ? h.z : head + (cont ? tail : 0u);
+    return h.x == epoch ? n : 0u;
 }
 
 // ====================================================================================
@@ -257,8 +410,9 @@ __device__ __forceinline__ LaneHit lane_lookup(const TableRef &tab, uint32_t key
 // ====================================================================================
 struct QInfo;
 struct CountParams {
-    TableRef tab;
-    const uint8_t *residues;  // the protein records, or the ORF amino acids (4-byte aligned)
+    const uint32_t *arena;
+    const uint4 *rec, *rec2;  // from kernel P: one each per residue position
+    uint32_t epoch;           // rec[i].x == epoch: the position's key is present
     // query groups (count_group.hip.inc)
     const struct QInfo *qinfo;
     const uint64_t *slot_off;   // exclusive scan of the table capacities
@@ -266,10 +420,10 @@ struct CountParams {
     const uint32_t *d_n_groups;
     const uint32_t *d_nq;
     uint32_t last_group_pass;   // this launch may clear group_first behind itself
-    // PositionHits pass (search_group_kernel MODE 1)
+    // PositionHits pass (count_group_kernel MODE 1)
     const uint64_t *pos_base;
     unsigned long long *pos_bits;
-    // merge of partial hit lists (search_group_kernel MODE 2)
+    // merge of partial hit lists (count_group_kernel MODE 2)
     const uint32_t *m_pid, *m_km, *m_fp;
     // tier input / overflow output lists
     const WorkItem *list;
@@ -397,51 +551,67 @@ __device__ __forceinline__ bool add_runs(const Table &tab, uint32_t x, uint32_t 
     return ok;
 }
 
-// G tier: one 64-position window of ONE query per call.  Every lane looks its own key up
-// (lane_lookup: the bucket's cells one lane at a time -- the G tier is rare, the cooperative 8-lane
-// probe lives in the group kernel), then the counter increments (KCombStore.Get + the id loop of
-// search.go:427-436): first ids with run merging, short lists lane by lane, long lists (arena)
-// spread over the whole wave.  No workgroup barriers inside.  COUNT_ONLY: only sum the postings
-// (G tier sizing pass).  `lut`: byte -> residue code, in LDS.
+// G tier: one 64-position window of ONE query per call: the counter increments (KCombStore.Get + the id
+// loop of search.go:427-436) from the probe's records: first ids with run merging, short lists lane by
+// lane, long lists (arena) spread over the whole wave.  No workgroup barriers inside.  COUNT_ONLY: only
+// sum the postings (G tier sizing pass).
+__device__ __forceinline__ uint32_t rec_id(const uint32_t *arena, const uint4 &h, const uint4 &c, uint32_t t)
+{
+    if (h.y & KH_ARENA_BIT) return t == 0u ? h.w : arena[(uint64_t)(h.y & ~KH_ARENA_BIT) * 4 + (t - 1u)];
+    switch (t) {
+    case 0: return h.y;
+    case 1: return h.z;
+    case 2: return h.w & ~KH_CONT_BIT;
+    case 3: return c.y;
+    case 4: return c.z;
+    default: return c.w;
+    }
+}
 template <class Table, bool COUNT_ONLY>
 __device__ __forceinline__ bool count_window(const CountParams &p, uint64_t aa_off, int32_t size, int32_t c0, const Table &tab,
-                                             PostCtr &c, const uint8_t *lut)
+                                             PostCtr &c)
 {
     const uint32_t lane = lane_id();
     const int32_t pos = c0 + (int32_t)lane;
-    LaneHit h;
-    h.cnt = 0;
-    h.c0 = h.c1 = make_uint4(KH_EMPTY_KEY, 0, 0, 0);
-    if (pos < size) {
-        uint32_t d0, d1, d2, sh, np = 0;
-        load_kmer_words(residue_words(p.residues), aa_off + (uint64_t)pos, d0, d1, d2, sh);
-        const uint32_t key = key_from_words(d0, d1, d2, sh, lut);
-        if (!(p.tab.n_shards > 1 && kh_shard_of(key, p.tab.n_shards) != p.tab.shard))
-            h = lane_lookup(p.tab, key, table_home_bucket(p.tab, key), np);
-    }
-    const bool arena = (h.c0.y & KH_ARENA_BIT) != 0u && h.cnt != 0u;
-    if (h.cnt != 0u) {
-        c.post += h.cnt;
-        if (arena) { c.lists++; c.lids += h.cnt - 1u; }
+    uint4 h = make_uint4(~p.epoch, 0, 0, 0), hc = make_uint4(0, 0, 0, 0);
+    if (pos < size) { h = p.rec[aa_off + (uint64_t)pos]; hc = p.rec2[aa_off + (uint64_t)pos]; }
+    const uint32_t cnt = rec_count(p.epoch, h, hc);
+    const bool arena = cnt != 0u && (h.y & KH_ARENA_BIT) != 0u;
+    if (cnt != 0u) {
+        c.post += cnt;
+        if (arena) { c.lists++; c.lids += cnt - 1u; }
     }
     if (COUNT_ONLY) return true;
     bool ok = true;
     uint32_t nnew = 0;
-    ok = add_runs(tab, h.cnt != 0u ? hit_id(p.tab, h, 0u) : KH_EMPTY_PID, (uint32_t)pos, nnew);
+    ok = add_runs(tab, cnt != 0u ? rec_id(p.arena, h, hc, 0u) : KH_EMPTY_PID, (uint32_t)pos, nnew);
     constexpr uint32_t SERIAL = 8;  // ids a lane adds on its own; the rest of a longer list is shared by the wave
-    const uint32_t n_ser = h.cnt < SERIAL ? h.cnt : SERIAL;
-    for (uint32_t t = 1; t < n_ser; t++) ok = tab.add_n(hit_id(p.tab, h, t), (uint32_t)pos, 1u, nnew) && ok;
-    unsigned long long big = __ballot(h.cnt > SERIAL);
+    const uint32_t n_ser = cnt < SERIAL ? cnt : SERIAL;
+    for (uint32_t t = 1; t < n_ser; t++) ok = tab.add_n(rec_id(p.arena, h, hc, t), (uint32_t)pos, 1u, nnew) && ok;
+    unsigned long long big = __ballot(cnt > SERIAL);
     while (big) {
         const int l = __ffsll((long long)big) - 1;
         big &= big - 1ull;
-        const uint32_t cnt_l = __shfl(h.cnt, l, 64), off_l = __shfl(h.c0.y & ~KH_ARENA_BIT, l, 64), pos_l = (uint32_t)c0 + (uint32_t)l;
+        const uint32_t cnt_l = __shfl(cnt, l, 64), off_l = __shfl(h.y & ~KH_ARENA_BIT, l, 64), pos_l = (uint32_t)c0 + (uint32_t)l;
         for (uint32_t t = SERIAL + lane; t < cnt_l; t += 64)
-            ok = tab.add_n(p.tab.arena[(uint64_t)off_l * 4 + (t - 1u)], pos_l, 1u, nnew) && ok;
+            ok = tab.add_n(p.arena[(uint64_t)off_l * 4 + (t - 1u)], pos_l, 1u, nnew) && ok;
     }
     const uint32_t wave_new = wave_total(nnew);
     if (lane == 0 && wave_new) atomicAdd(tab.nd, wave_new);
     return __all(ok);
+}
+
+// sets bits [b, e) of the not-a-k-mer-start bitmap
+__device__ __forceinline__ void mark_invalid_range(unsigned long long *invalid, uint64_t b, uint64_t e)
+{
+    while (b < e) {
+        const uint64_t w = b >> 6;
+        const uint64_t hi = ((w + 1) << 6) < e ? ((w + 1) << 6) : e;
+        const unsigned nb = (unsigned)(hi - b);
+        const unsigned long long m = (nb == 64 ? ~0ull : ((1ull << nb) - 1ull)) << (b & 63);
+        atomicOr(&invalid[w], m);
+        b = hi;
+    }
 }
 
 #include "count_group.hip.inc"
@@ -485,11 +655,9 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
 {
     constexpr int WAVES = G_WAVES;
     __shared__ uint32_t s_nd, s_fail, s_cursor;
-    __shared__ uint8_t s_lut[256];
     __shared__ unsigned long long s_post, s_off, s_base;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    for (uint32_t i = tid; i < 256; i += 64 * WAVES) s_lut[i] = (uint8_t)kh_residue_code((uint8_t)i);
     const uint32_t n_items = *p.list_count < p.list_cap ? *p.list_count : p.list_cap;
     unsigned long long tot_hits = 0;
     PostCtr pc;
@@ -505,7 +673,7 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
         // pass 1: exact number of postings (an upper bound of the distinct proteins)
         pc.clear();
         for (int32_t r0 = 64 * (int32_t)wv; r0 < size; r0 += 64 * WAVES)
-            count_window<NullTable, true>(p, wi.aa_off, size, r0, nt, pc, s_lut);
+            count_window<NullTable, true>(p, wi.aa_off, size, r0, nt, pc);
         {
             const unsigned long long wp = wave_total(pc.post);
             if (lane == 0 && wp) atomicAdd(&s_post, wp);
@@ -542,7 +710,7 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
         // pass 2: count
         pc.clear();
         for (int32_t r0 = 64 * (int32_t)wv; r0 < size; r0 += 64 * WAVES) {
-            const bool ok = count_window<GlobalTable, false>(p, wi.aa_off, size, r0, gt, pc, s_lut);
+            const bool ok = count_window<GlobalTable, false>(p, wi.aa_off, size, r0, gt, pc);
             if (!ok) s_fail = 1;
         }
         __syncthreads();
@@ -626,10 +794,8 @@ __global__ __launch_bounds__(64 * G_WAVES) void positions_global_kernel(CountPar
 {
     constexpr int WAVES = G_WAVES;
     __shared__ uint32_t s_nd;
-    __shared__ uint8_t s_lut[256];
     __shared__ unsigned long long s_off;
     const uint32_t tid = threadIdx.x, wv = tid >> 6;
-    for (uint32_t i = tid; i < 256; i += 64 * WAVES) s_lut[i] = (uint8_t)kh_residue_code((uint8_t)i);
     const uint32_t n_items = *p.list_count < p.list_cap ? *p.list_count : p.list_cap;
     PostCtr pc;
     for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
@@ -667,7 +833,7 @@ __global__ __launch_bounds__(64 * G_WAVES) void positions_global_kernel(CountPar
         pc.clear();
         bool ok = true;
         for (int32_t r0 = 64 * (int32_t)wv; r0 < size; r0 += 64 * WAVES)
-            ok = count_window<BitsTable, false>(p, wi.aa_off, size, r0, bt, pc, s_lut) && ok;
+            ok = count_window<BitsTable, false>(p, wi.aa_off, size, r0, bt, pc) && ok;
         if (!ok && (tid & 63u) == 0) atomicOr(p.status, (uint32_t)ST_G_TABLE_FULL);
         __syncthreads();
     }
@@ -834,6 +1000,9 @@ struct kaamer_workspace {
     kaamer_query_meta *d_q;
     uint32_t *d_nq;
     unsigned long long *d_n_pos;
+    unsigned long long *d_valid;        // one bit per residue position: not a k-mer start
+    uint4 *d_rec;                       // the probe's records: pos_cap heads, then pos_cap continuations
+    uint32_t rec_epoch;                 // tag of the current batch's records
     uint32_t *d_q_cnt;
     unsigned long long *d_pool_cursor;  // CURSOR_STRIDE apart: G-tier tail cursor, G arena cursor (count), G arena cursor (positions)
     WorkItem *d_lists;                  // [N_LISTS][q_cap] (only the G tier's overflow list is used)
@@ -909,16 +1078,16 @@ template <class T> static int dev_alloc(T **p, size_t n)
 
 static void launch_group(const CountParams &p, int grid, bool firstpos, hipStream_t s)
 {
-    if (firstpos) hipLaunchKernelGGL((search_group_kernel<true, 0>), dim3(grid), dim3(64 * GRP_WAVES), 0, s, p);
-    else hipLaunchKernelGGL((search_group_kernel<false, 0>), dim3(grid), dim3(64 * GRP_WAVES), 0, s, p);
+    if (firstpos) hipLaunchKernelGGL((count_group_kernel<true, 0>), dim3(grid), dim3(64 * GRP_WAVES), 0, s, p);
+    else hipLaunchKernelGGL((count_group_kernel<false, 0>), dim3(grid), dim3(64 * GRP_WAVES), 0, s, p);
 }
 static void launch_group_positions(const CountParams &p, int grid, hipStream_t s)
 {
-    hipLaunchKernelGGL((search_group_kernel<false, 1>), dim3(grid), dim3(64 * GRP_WAVES), 0, s, p);
+    hipLaunchKernelGGL((count_group_kernel<false, 1>), dim3(grid), dim3(64 * GRP_WAVES), 0, s, p);
 }
 static void launch_group_merge(const CountParams &p, int grid, hipStream_t s)
 {
-    hipLaunchKernelGGL((search_group_kernel<true, 2>), dim3(grid), dim3(64 * GRP_WAVES), 0, s, p);
+    hipLaunchKernelGGL((count_group_kernel<true, 2>), dim3(grid), dim3(64 * GRP_WAVES), 0, s, p);
 }
 
 extern "C" {
@@ -982,7 +1151,7 @@ void kaamer_workspace_free(kaamer_workspace *ws)
 {
     if (!ws) return;
     (void)hipSetDevice(ws->device);
-    void *bufs[] = { ws->d_q, ws->d_nq, ws->d_n_pos, ws->d_cnt3, ws->d_off3, ws->d_n6, ws->d_long_seq, ws->d_long_np, ws->d_pcnt3, ws->d_n_piece_items, ws->d_piece_base, ws->d_poff3,
+    void *bufs[] = { ws->d_q, ws->d_nq, ws->d_n_pos, ws->d_valid, ws->d_rec, ws->d_cnt3, ws->d_off3, ws->d_n6, ws->d_long_seq, ws->d_long_np, ws->d_pcnt3, ws->d_n_piece_items, ws->d_piece_base, ws->d_poff3,
                      ws->d_tmp_meta, ws->d_orf_aa, ws->d_starts_alt, ws->d_q_cnt, ws->d_csr_off, ws->d_c_pid, ws->d_c_km, ws->d_c_fp,
                      ws->d_pool_cursor, ws->d_lists, ws->d_list_counts, ws->d_status_out, ws->d_qinfo, ws->d_slots,
                      ws->d_slot_off, ws->d_group_first, ws->d_n_groups, ws->d_pos_words, ws->d_pos_base, ws->d_pos_off, ws->d_pos_bits, ws->d_g_keys,
@@ -1033,17 +1202,20 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     }
     // the reference fills PositionHits only for nucleotide/reads input or with -pos (search.go:416)
     ws->firstpos = opts->first_pos == 1 || (opts->first_pos == 0 && (opts->seq_type == KAAMER_NUCLEOTIDE || opts->seq_type == KAAMER_READS));
-    int grp_per_cu = 0;
+    int grp_per_cu = 0, p_per_cu = 0;
     hipError_t oe = ws->firstpos
-        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&grp_per_cu, search_group_kernel<true, 0>, 64 * GRP_WAVES, 0)
-        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&grp_per_cu, search_group_kernel<false, 0>, 64 * GRP_WAVES, 0);
+        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&grp_per_cu, count_group_kernel<true, 0>, 64 * GRP_WAVES, 0)
+        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&grp_per_cu, count_group_kernel<false, 0>, 64 * GRP_WAVES, 0);
+    if (oe == hipSuccess) oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&p_per_cu, probe_kernel, 64 * P_WAVES, 0);
     if (oe != hipSuccess) { delete ws; return kaamer_fail(KAAMER_E_HIP, "occupancy query: %s", hipGetErrorString(oe)); }
+    if (p_per_cu < 1) p_per_cu = 1;
     hipDeviceProp_t prop;
     hipError_t pe = hipGetDeviceProperties(&prop, ix->device);
     if (pe != hipSuccess) { delete ws; return kaamer_fail(KAAMER_E_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(pe)); }
     if (grp_per_cu < 1) grp_per_cu = 1;
     ws->n_cu = prop.multiProcessorCount;
     ws->grp_grid = ws->n_cu * grp_per_cu;
+    ws->p_grid = ws->n_cu * p_per_cu;
     ws->g_grid = ws->n_cu / 2;  // the G tier is rare; its last workgroup also finalizes the batch (one atomic per workgroup)
     // a table has at most max(64, 3 x SizeInKmer) slots
     {
@@ -1065,6 +1237,10 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     rc = dev_alloc(&ws->d_q, ws->q_cap);
     if (!rc) rc = dev_alloc(&ws->d_nq, 1);
     if (!rc) rc = dev_alloc(&ws->d_n_pos, 1);
+    if (!rc) rc = dev_alloc(&ws->d_valid, (size_t)(ws->pos_cap / 64 + 2));
+    if (!rc) rc = dev_alloc(&ws->d_rec, (size_t)ws->pos_cap * 2);
+    // a record counts only if its first word carries the current batch's tag (tags start at 1)
+    if (!rc && hipMemset(ws->d_rec, 0, (size_t)ws->pos_cap * sizeof(uint4)) != hipSuccess) rc = kaamer_fail(KAAMER_E_HIP, "memset");
     if (!rc && ws->nucleotide) {
         const size_t n6 = (size_t)ws->max_seqs * 6;
         rc = dev_alloc(&ws->d_cnt3, 3 * n6);
@@ -1182,6 +1358,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     if (!nucl && seq_type != KAAMER_PROTEIN) return kaamer_fail(KAAMER_E_ARG, "search_device: unknown sequence type %d", seq_type);
     if (nucl != ws->nucleotide) return kaamer_fail(KAAMER_E_ARG, "workspace was created for %s input", ws->nucleotide ? "nucleotide" : "protein");
     if (n_seqs > ws->max_seqs) return kaamer_fail(KAAMER_E_CAPACITY, "batch of %u sequences exceeds workspace max_seqs %u", n_seqs, ws->max_seqs);
+    if (ws->pos_cap > 0xFFFFFFF0ull) return kaamer_fail(KAAMER_E_CAPACITY, "a batch holds at most 2^32 residue positions");
     if (seq_bytes > ws->opts.max_seq_bytes) return kaamer_fail(KAAMER_E_CAPACITY, "batch of %llu bytes exceeds workspace max_seq_bytes", (unsigned long long)seq_bytes);
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(ix->device));
@@ -1204,6 +1381,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         HIPCHK(hipMemsetAsync(ws->d_pool_cursor, 0, (size_t)3 * CURSOR_STRIDE * sizeof(unsigned long long), s));
         HIPCHK(hipMemsetAsync(ws->d_list_counts, 0, N_SMALL_SLOTS * sizeof(uint32_t), s));
         HIPCHK(hipMemsetAsync(ws->d_counter_replicas, 0, sizeof(unsigned long long) * CTR_REPLICAS * CTR_N, s));
+        HIPCHK(hipMemsetAsync(ws->d_valid, 0, (size_t)(ws->pos_cap / 64 + 2) * sizeof(unsigned long long), s));
     }
     ws->clean = false;
 
@@ -1218,7 +1396,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         PrepLayoutParams pl;
         memset(&pl, 0, sizeof pl);
         pl.seqs = d_seqs; pl.offsets = d_offsets; pl.n_seqs = n_seqs;
-        pl.q = ws->d_q; pl.d_nq = ws->d_nq; pl.d_n_pos = ws->d_n_pos; pl.qinfo = ws->d_qinfo;
+        pl.q = ws->d_q; pl.d_nq = ws->d_nq; pl.d_n_pos = ws->d_n_pos; pl.invalid = ws->d_valid; pl.qinfo = ws->d_qinfo;
         pl.hit_off = ws->d_hit_off; pl.q_cnt = ws->d_q_cnt;
         pl.E = ws->d_slot_off; pl.group_first = ws->d_group_first; pl.group_start = ws->d_group_start;
         pl.d_n_groups = ws->d_n_groups; pl.groups_cap = ws->groups_cap; pl.chain = ws->d_chain;
@@ -1288,7 +1466,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         hipLaunchKernelGGL(translate_short_kernel<true>, dim3(sgrid), dim3(64 * TS_WAVES), 0, s, tp);
         hipLaunchKernelGGL(orf_order_kernel, dim3(ws->n_cu * 4), dim3(256), 0, s, ws->d_tmp_meta, tp.off_orf, n_seqs, ws->d_q,
                            ws->d_nq, ws->d_n_pos, tp.off_aa, (uint64_t)ws->q_cap, status);
-        hipLaunchKernelGGL(prep_orf_kernel, dim3(ws->n_cu * 4), dim3(pb), 0, s, ws->d_q, ws->d_nq,
+        hipLaunchKernelGGL(prep_orf_kernel, dim3(ws->n_cu * 4), dim3(pb), 0, s, ws->d_q, ws->d_nq, ws->d_valid, ws->d_n_pos,
                            ws->d_qinfo, ws->d_slots, ws->d_hit_off, ws->d_q_cnt);
         residues = ws->d_orf_aa;
         pos_bound = ws->aa_cap;
@@ -1298,19 +1476,42 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     // ---- query groups: table layout, first query of each group, schedule (protein: done with the prep)
     if (nucl) launch_layout(ws, nq_bound, status, s);
 
-    if (timed) HIPCHK(hipEventRecord(ev[1], s));
-    // ---- the search kernel: probe + count
-    CountParams p;
-    memset(&p, 0, sizeof p);
-    p.tab.cells = reinterpret_cast<const uint4 *>(ix->d_buckets);
-    p.tab.arena = ix->d_arena;
-    p.tab.n_buckets = ix->hdr.n_buckets;
-    p.tab.n_shards = ix->hdr.n_shards;
-    p.tab.shard = ix->hdr.shard;
+    // ---- kernel P: flat probe
+    ProbeParams pp;
+    memset(&pp, 0, sizeof pp);
+    pp.tab.cells = reinterpret_cast<const uint4 *>(ix->d_buckets);
+    pp.tab.arena = ix->d_arena;
+    pp.tab.n_buckets = ix->hdr.n_buckets;
+    pp.tab.n_shards = ix->hdr.n_shards;
+    pp.tab.shard = ix->hdr.shard;
     // nontemporal when the batch is small against the table (a bucket is then read once per batch); a
     // 1 M-read batch touches every bucket several times and wants them cached
-    p.tab.nontemporal = pos_bound < ix->hdr.n_buckets ? 1u : 0u;
-    p.residues = residues;
+    pp.tab.nontemporal = pos_bound < ix->hdr.n_buckets ? 1u : 0u;
+    if (const char *e = getenv("KAAMER_NT")) pp.tab.nontemporal = (uint32_t)atoi(e);  // tuning experiments only
+    pp.residues = residues;
+    pp.invalid = ws->d_valid;
+    pp.d_n_pos = ws->d_n_pos;
+    pp.rec = ws->d_rec;
+    pp.rec2 = ws->d_rec + ws->pos_cap;
+    if (++ws->rec_epoch == 0u) {  // the tag wrapped (2^32 batches): old records must not be taken for new ones
+        HIPCHK(hipMemsetAsync(ws->d_rec, 0, (size_t)ws->pos_cap * sizeof(uint4), s));
+        ws->rec_epoch = 1u;
+    }
+    pp.epoch = ws->rec_epoch;
+    pp.counters = ws->d_counter_replicas;
+    uint64_t p_blocks = (pos_bound / 64 + 1 + P_WAVES - 1) / P_WAVES;
+    if (p_blocks > (uint64_t)ws->p_grid) p_blocks = ws->p_grid;
+    if (p_blocks < 1) p_blocks = 1;
+    if (timed) HIPCHK(hipEventRecord(ev[1], s));
+    hipLaunchKernelGGL(probe_kernel, dim3((unsigned)p_blocks), dim3(64 * P_WAVES), 0, s, pp);
+    if (timed) HIPCHK(hipEventRecord(ev[2], s));
+    // ---- kernel C: counting
+    CountParams p;
+    memset(&p, 0, sizeof p);
+    p.arena = ix->d_arena;
+    p.rec = ws->d_rec;
+    p.rec2 = ws->d_rec + ws->pos_cap;
+    p.epoch = ws->rec_epoch;
     p.qinfo = ws->d_qinfo;
     p.slot_off = ws->d_slot_off;
     p.group_first = ws->d_group_first;
@@ -1349,7 +1550,6 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         grp_blocks = gb;
         launch_group(pc, (int)gb, ws->firstpos, s);
     }
-    if (timed) HIPCHK(hipEventRecord(ev[2], s));
     CountParams pg = p;
     pg.list = list_ptr(LIST_G); pg.list_count = ws->d_list_counts + LIST_G;
     int g_grid = ws->g_grid;
@@ -1430,6 +1630,7 @@ int kaamer_merge_device(kaamer_workspace *ws, const uint64_t *d_ent_off, const u
         HIPCHK(hipMemsetAsync(ws->d_pool_cursor, 0, (size_t)3 * CURSOR_STRIDE * sizeof(unsigned long long), s));
         HIPCHK(hipMemsetAsync(ws->d_list_counts, 0, N_SMALL_SLOTS * sizeof(uint32_t), s));
         HIPCHK(hipMemsetAsync(ws->d_counter_replicas, 0, sizeof(unsigned long long) * CTR_REPLICAS * CTR_N, s));
+        HIPCHK(hipMemsetAsync(ws->d_valid, 0, (size_t)(ws->pos_cap / 64 + 2) * sizeof(unsigned long long), s));
     }
     ws->clean = false;
     uint32_t *status = ws->d_list_counts + SLOT_STATUS;

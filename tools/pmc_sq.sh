@@ -11,7 +11,7 @@ for d in ("sq","sq2"):
     if not fs: continue
     acc={}
     for r in csv.DictReader(open(sorted(fs)[-1])):
-        if "search_group" in r["Kernel_Name"]:
-            acc.setdefault(r["Counter_Name"],[]).append(float(r["Counter_Value"]))
+        if "count_group" in r["Kernel_Name"] or "probe_kernel" in r["Kernel_Name"]:
+            acc.setdefault(r["Kernel_Name"][:12]+" "+r["Counter_Name"],[]).append(float(r["Counter_Value"]))
     for k,v in acc.items(): print("%-24s %14.0f (n=%d)"%(k, sum(v)/len(v), len(v)))
 PY
