@@ -35,6 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+BUCKET_BYTES = 64      # kaamer_layout.h: 4 cells of 16 B
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 
 
@@ -116,7 +117,7 @@ def main():
                     help="batches pushed back to back in one step (default 200 protein batches / 3 read batches: ~25 ms)")
     ap.add_argument("--distinct-batches", type=int, default=8,
                     help="different pre-generated batches the steps rotate over (their bucket footprint exceeds the Infinity Cache)")
-    ap.add_argument("--load-factor", type=float, default=0.5)
+    ap.add_argument("--load-factor", type=float, default=0.0, help="cells in use / cells of the table (0 = the library's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--check", type=int, default=50, help="queries checked against the oracle after timing")
@@ -173,7 +174,7 @@ def main():
     t0 = time.time()
     ix = api.Index.from_image(img, local_rank)
     img.close()
-    table_bytes = st["n_buckets"] * 128 + st["arena_words"] * 4
+    table_bytes = st["n_buckets"] * BUCKET_BYTES + st["arena_words"] * 4
     log("index resident in HBM (%.2f GB) in %.1fs" % (table_bytes / 1e9, time.time() - t0))
 
     # ---- the batches: same generator, a different seed per batch (and per rank: replicas search their own batches)
@@ -288,7 +289,7 @@ def main():
     #       and 40 B of meta written per ORF), G tier (rare)
     c = avg
     hit_b = 12 if (nucl or sharded_mode) else 8
-    search_bytes = c["n_in"] + 128 * c["n_probe"] + 4 * c["n_list_ids"] + 36 * c["n_queries"] + hit_b * c["n_hits"]
+    search_bytes = c["n_in"] + BUCKET_BYTES * c["n_probe"] + 4 * c["n_list_ids"] + 36 * c["n_queries"] + hit_b * c["n_hits"]
     if nucl:
         nt = float(np.mean([len(q[0]) for q in batches]))
         rest_bytes = 2 * nt + 48 * args.queries + c["n_in"] + 64 * c["n_queries"]

@@ -42,17 +42,19 @@
 #define KH_EMPTY_PID 0xFFFFFFFFu   /* "no id" of the counting tables and result arrays */
 #define KH_NO_ID 0x7FFFFFFFu       /* unused id word of a cell */
 #define KH_MAX_PID 0x7FFFFFFEu
-#define KH_CELLS_PER_BUCKET 8
-#define KH_BUCKET_BYTES 128
+#ifndef KH_CELLS_PER_BUCKET
+#define KH_CELLS_PER_BUCKET 4
+#endif
+#define KH_BUCKET_BYTES (16 * KH_CELLS_PER_BUCKET)
 #define KH_ARENA_BIT 0x80000000u   /* in w1 */
 #define KH_CONT_BIT 0x80000000u    /* in w3 of an inline head cell */
 #define KH_INLINE_IDS 3            /* ids in a head cell */
 #define KH_CELL_IDS_MAX 6          /* head + one continuation cell */
 #define KH_IMAGE_MAGIC 0x32544B4852454D41ull /* "AMERHKT2" little-endian tag */
-#define KH_IMAGE_VERSION 2
+#define KH_IMAGE_VERSION (0x200 + KH_CELLS_PER_BUCKET)  /* layout 2, cells per bucket */
 
 struct alignas(16) kh_cell { uint32_t key, w1, w2, w3; };
-struct alignas(128) kh_bucket { kh_cell c[KH_CELLS_PER_BUCKET]; };
+struct alignas(KH_BUCKET_BYTES) kh_bucket { kh_cell c[KH_CELLS_PER_BUCKET]; };
 
 // murmur3 finalizer
 KH_HD uint32_t kh_mix32(uint32_t h)

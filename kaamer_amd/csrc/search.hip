@@ -171,6 +171,10 @@ __device__ __forceinline__ uint32_t table_home_bucket(const TableRef &t, uint32_
     return __umulhi(rest, (uint32_t)t.n_buckets);
 }
 
+// c ? a : b on VALUES.  (`c ? x.y : z.y` on lvalues is an lvalue: clang selects between the two ADDRESSES and loads
+// once, which pins a register array in scratch memory.)
+__device__ __forceinline__ uint32_t sel(bool c, uint32_t a, uint32_t b) { return c ? a : b; }
+
 // One lane looks a key up on its own (rare paths: the key's home bucket is full and does not hold it;
 // the G tier).  Returns the number of ids (0 = absent); c0 = the matching cell, c1 = its continuation.
 struct LaneHit {
@@ -192,13 +196,24 @@ __device__ __forceinline__ LaneHit lane_lookup(const TableRef &tab, uint32_t key
     for (uint64_t tries = 0; tries < tab.n_buckets; tries++) {
         n_probe++;
         const uint4 *cells = tab.cells + (uint64_t)bucket * KH_CELLS_PER_BUCKET;
-        // the whole bucket in one go: eight independent loads, one memory round trip
-        const uint4 c0 = cells[0], c1 = cells[1], c2 = cells[2], c3 = cells[3], c4 = cells[4], c5 = cells[5], c6 = cells[6], c7 = cells[7];
-#define KH_TRY(a, b) if (a.x == key) { h.c0 = a; h.c1 = b; h.cnt = cell_count(a, b); return h; }
-        KH_TRY(c0, c1) KH_TRY(c1, c2) KH_TRY(c2, c3) KH_TRY(c3, c4) KH_TRY(c4, c5) KH_TRY(c5, c6) KH_TRY(c6, c7)
-#undef KH_TRY
-        if (c7.x == key) { h.c0 = c7; h.cnt = cell_count(c7, h.c1); return h; }
-        if (c7.x == KH_EMPTY_KEY) return h;  // a bucket with a free cell ends the probe sequence
+        // the whole bucket in one go: independent loads, one memory round trip
+        uint4 c[KH_CELLS_PER_BUCKET];
+#pragma unroll
+        for (int i = 0; i < KH_CELLS_PER_BUCKET; i++) c[i] = cells[i];
+        // selects on values with constant indices (no early exit inside the unrolled loop): the cells stay in registers
+        bool found = false;
+        uint4 h0 = make_uint4(KH_EMPTY_KEY, 0, 0, 0), h1 = make_uint4(KH_EMPTY_KEY, 0, 0, 0);
+#pragma unroll
+        for (int i = KH_CELLS_PER_BUCKET - 1; i >= 0; i--) {
+            const bool mm = c[i].x == key;
+            found = found || mm;
+            h0.x = sel(mm, c[i].x, h0.x); h0.y = sel(mm, c[i].y, h0.y); h0.z = sel(mm, c[i].z, h0.z); h0.w = sel(mm, c[i].w, h0.w);
+            if (i + 1 < KH_CELLS_PER_BUCKET) {
+                h1.x = sel(mm, c[i + 1].x, h1.x); h1.y = sel(mm, c[i + 1].y, h1.y); h1.z = sel(mm, c[i + 1].z, h1.z); h1.w = sel(mm, c[i + 1].w, h1.w);
+            }
+        }
+        if (found) { h.c0 = h0; h.c1 = h1; h.cnt = cell_count(h0, h1); return h; }
+        if (c[KH_CELLS_PER_BUCKET - 1].x == KH_EMPTY_KEY) return h;  // a bucket with a free cell ends the probe sequence
         bucket = bucket + 1u == (uint32_t)tab.n_buckets ? 0u : bucket + 1u;
     }
     return h;
@@ -235,9 +250,6 @@ struct ProbeParams {
 #define P_WAVES 4
 #define P_RING 128u  /* deferred lookups per wave (a power of two): fewer than 64 waiting + the 64 of a window */
 
-// c ? a : b on VALUES.  (`c ? x.y : z.y` on lvalues is an lvalue: clang selects between the two ADDRESSES and loads
-// once, which pins a register array in scratch memory.)
-__device__ __forceinline__ uint32_t sel(bool c, uint32_t a, uint32_t b) { return c ? a : b; }
 
 #define KH_NO_KEY 0xFFFFFFFDu  /* "no lookup for this position": equals no cell key (valid keys, 0xFFFFFFFF empty, 0xFFFFFFFE continuation) */
 
@@ -255,102 +267,28 @@ __global__ __launch_bounds__(64 * P_WAVES, 6) void probe_kernel(ProbeParams p)
     uint32_t c_lookup = 0, c_probe = 0, c_found = 0;
     uint8_t *stage = s_stage[wv];
     const uint32_t n_buckets = (uint32_t)p.tab.n_buckets;
-    // Lookups whose home bucket is full and does not hold the key (a few per cent) go on in the NEXT bucket.  Waiting for
-    // that second request inside the window would stall the whole wave in six windows out of seven, so such lookups are
-    // put on a ring in LDS (key, position) and looked up later, 64 at a time, as a window of their own (STEP 1).
-    __shared__ uint32_t s_ring[P_WAVES][2][P_RING];
-    uint32_t *const ring_key = s_ring[wv][0], *const ring_pos = s_ring[wv][1];
+    // Lookups whose bucket is full and does not hold the key (a few per cent) go on in the NEXT bucket of the probe
+    // sequence.  Waiting for that second request inside the window would stall the whole wave in six windows out of seven,
+    // so such lookups are put on a ring in LDS (key, position, buckets walked) and looked up later, 64 at a time, as an
+    // iteration of their own through the same code.  The loop body is ONE straight line for both kinds of iteration and
+    // every global load and store in it is issued unconditionally (idle lanes and idle iterations touch harmless
+    // addresses): the compiler's s_waitcnt vmcnt(N) then counts exactly, and waiting for the prefetched inputs of the next
+    // window does not wait for this window's record stores.
+    __shared__ uint32_t s_ring[P_WAVES][3][P_RING];
+    // Records leave through LDS: the lane whose cell matches parks the record in the slot of the lane that asked, and
+    // every lane then stores its own position's record -- one coalesced 1 KB store per window instead of ~45 separate
+    // 16-byte stores.  (Measured: the scattered stores cost as many memory requests as the bucket reads themselves, and
+    // the memory system serves ~53e9 requests/s, loads and stores together.)
+    __shared__ uint4 s_rec[P_WAVES][64];
+    uint4 *const srec = s_rec[wv];
+    uint32_t *const ring_key = s_ring[wv][0], *const ring_pos = s_ring[wv][1], *const ring_step = s_ring[wv][2];
     uint32_t ring_head = 0, ring_n = 0;  // wave-uniform
-
-    // One window: `key` = the lane's key (KH_NO_KEY: none), its record at rec[base + off]; STEP = buckets past the home
-    // bucket.  Issue and consume are separate so that the next window's prefetch loads can be issued in between: every
-    // load of the loop is unconditional and in a fixed order, and the compiler's vmcnt(N) waits then count exactly.
-    struct Buckets { uint4 ld[2][4]; uint32_t rk[2], ro[2]; };
-    auto issue_window = [&](auto step_tag, uint32_t key, uint32_t off, Buckets &q) {
-        constexpr uint32_t STEP = decltype(step_tag)::value;
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-            q.rk[r] = __shfl(key, 32 * r + (int)pair, 64);  // round r serves the keys of lanes 32r .. 32r+31
-            q.ro[r] = STEP == 0u ? 32u * (uint32_t)r + pair : __shfl(off, 32 * r + (int)pair, 64);
-            uint32_t bucket = 0u;
-            if (q.rk[r] != KH_NO_KEY) {
-                bucket = table_home_bucket(p.tab, q.rk[r]) + STEP;
-                if (STEP != 0u && bucket >= n_buckets) bucket -= n_buckets;
-            }
-            const uint4 *src = p.tab.cells + (uint64_t)bucket * KH_CELLS_PER_BUCKET + sub;
-#pragma unroll
-            for (int i = 0; i < 4; i++) q.ld[r][i] = load_cell(src + 2 * i, p.tab.nontemporal);
-        }
-        c_probe += key != KH_NO_KEY ? 1u : 0u;
-    };
-    auto consume_window = [&](auto step_tag, unsigned long long base, const Buckets &q) {
-        constexpr uint32_t STEP = decltype(step_tag)::value;
-        uint4 *const recw = p.rec + base, *const rec2w = p.rec2 + base;  // scalar bases, 32-bit lane offsets
-#pragma unroll
-        for (int r = 0; r < 2; r++) {
-            const uint32_t rk = q.rk[r], ro = q.ro[r];
-            const uint4 l0 = q.ld[r][0], l1 = q.ld[r][1], l2 = q.ld[r][2], l3 = q.ld[r][3];
-            // my matching cell, if any (a key is in at most one cell); selects on values, constant indices only
-            const bool m0 = l0.x == rk, m1 = l1.x == rk, m2 = l2.x == rk, m3 = l3.x == rk;
-            const bool m = m0 || m1 || m2 || m3;
-            const uint32_t mi = m0 ? 0u : m1 ? 1u : m2 ? 2u : m3 ? 3u : 4u;
-            // the other lane of the pair: did it match, and in which of its cells (quad_perm [1,0,3,2])
-            const uint32_t pmi = (uint32_t)__builtin_amdgcn_update_dpp(4, (int)mi, 0xB1, 0xf, 0xf, false);
-            if (m) {
-                recw[ro] = make_uint4(p.epoch, sel(m0, l0.y, sel(m1, l1.y, sel(m2, l2.y, l3.y))), sel(m0, l0.z, sel(m1, l1.z, sel(m2, l2.z, l3.z))),
-                                      sel(m0, l0.w, sel(m1, l1.w, sel(m2, l2.w, l3.w))));
-                c_found++;
-            }
-            // the cell after the partner's matching cell is mine: partner cell (1-s) + 2 pmi -> my piece pmi + (1-s)
-            const uint32_t k = pmi + 1u - sub;
-            const bool k0 = k == 0u, k1 = k == 1u, k2 = k == 2u;
-            const uint32_t cx = sel(k0, l0.x, sel(k1, l1.x, sel(k2, l2.x, l3.x)));
-            if (k < 4u && cx == KH_CONT_KEY && pmi < 4u)
-                rec2w[ro] = make_uint4(cx, sel(k0, l0.y, sel(k1, l1.y, sel(k2, l2.y, l3.y))), sel(k0, l0.z, sel(k1, l1.z, sel(k2, l2.z, l3.z))),
-                                       sel(k0, l0.w, sel(k1, l1.w, sel(k2, l2.w, l3.w))));
-            // the key is in neither half of this bucket, and the bucket has no free cell (its last cell, held by the odd
-            // lane, is in use): the lookup goes on
-            const bool wk = sub == 1u && !m && pmi >= 4u && l3.x != KH_EMPTY_KEY && rk != KH_NO_KEY;
-            const unsigned long long W = __ballot(wk);
-            if (W) {  // wave-uniform
-                if (STEP == 0u) {
-                    if (wk) {
-                        const uint32_t slot = (ring_head + ring_n + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(W >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)W, 0u))) & (P_RING - 1u);
-                        ring_key[slot] = rk;
-                        ring_pos[slot] = (uint32_t)base + ro;  // positions fit 32 bits (checked on the host)
-                    }
-                    ring_n += (uint32_t)__popcll(W);
-                } else if (wk) {  // full again (a fraction of a per cent of those): this lane walks on alone
-                    uint32_t bk = table_home_bucket(p.tab, rk) + STEP + 1u;
-                    if (bk >= n_buckets) bk -= n_buckets;
-                    const LaneHit h = lane_lookup(p.tab, rk, bk, c_probe);
-                    if (h.cnt != 0u) {
-                        recw[ro] = make_uint4(p.epoch, h.c0.y, h.c0.z, h.c0.w);
-                        if (!(h.c0.y & KH_ARENA_BIT) && (h.c0.w & KH_CONT_BIT)) rec2w[ro] = h.c1;
-                        c_found++;
-                    }
-                }
-            }
-        }
-    };
-    // up to 64 deferred lookups from the ring, one bucket further
-    auto drain_ring = [&]() {
-        const uint32_t n = ring_n < 64u ? ring_n : 64u;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        uint32_t key = KH_NO_KEY, off = 0u;
-        if (lane < n) { key = ring_key[(ring_head + lane) & (P_RING - 1u)]; off = ring_pos[(ring_head + lane) & (P_RING - 1u)]; }
-        ring_head = (ring_head + n) & (P_RING - 1u);
-        ring_n -= n;
-        Buckets q;
-        issue_window(std::integral_constant<uint32_t, 1u>(), key, off, q);
-        consume_window(std::integral_constant<uint32_t, 1u>(), 0ull, q);
-    };
+    constexpr int PIECES = KH_CELLS_PER_BUCKET / 2;  // cells per lane: lane s of a pair holds cells s, s+2, ...
 
     const unsigned long long stride = (unsigned long long)gridDim.x * P_WAVES;
     unsigned long long w = (unsigned long long)blockIdx.x * P_WAVES + wv;
-    // software pipeline: the bitmap word and the residues of the NEXT window are loaded behind the bucket loads of the
-    // current one.  Windows and reads past the end are clamped (the positions involved are marked invalid or unused).
+    // the bitmap word and the residues of the NEXT window are loaded behind the bucket loads of the current one;
+    // windows and reads past the end are clamped (the positions involved are marked invalid or unused)
     unsigned long long mask = 0;
     uint32_t ra = 0, rb = 0;
     auto fetch = [&](unsigned long long win, unsigned long long &m, uint32_t &a, uint32_t &b) {
@@ -360,31 +298,123 @@ __global__ __launch_bounds__(64 * P_WAVES, 6) void probe_kernel(ProbeParams p)
         a = p.residues[i0 < last ? i0 : last];
         b = p.residues[i0 + 64 < last ? i0 + 64 : last];  // lanes 0..5 hold the halo
     };
-    if (w < n_win) fetch(w, mask, ra, rb);
+    if (n_win) fetch(w, mask, ra, rb);
 
-    for (; w < n_win; w += stride) {
-        const unsigned long long base = w << 6;
-        const unsigned long long valid = ~mask;
-        if (lane == 0) p.invalid[w] = 0ull;  // leave the bitmap clean for the next batch
-        stage[lane] = s_lut[ra];
-        if (lane < 6) stage[64 + lane] = s_lut[rb];
+    while (n_win) {
+        const bool ring = ring_n >= 64u || (w >= n_win && ring_n > 0u);  // wave-uniform: this iteration serves the ring
+        if (!ring && w >= n_win) break;
+        unsigned long long base = 0;
+        uint32_t key = KH_NO_KEY, off = 0, step = 0;
+        if (ring) {
+            const uint32_t n = ring_n < 64u ? ring_n : 64u;
+            if (lane < n) {
+                const uint32_t slot = (ring_head + lane) & (P_RING - 1u);
+                key = ring_key[slot]; off = ring_pos[slot]; step = ring_step[slot];
+            }
+            ring_head = (ring_head + n) & (P_RING - 1u);
+            ring_n -= n;
+        } else {
+            base = w << 6;
+            off = lane;
+            stage[lane] = s_lut[ra];
+            if (lane < 6) stage[64 + lane] = s_lut[rb];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint8_t *st = stage + lane;
+            key = kh_key_from_codes(st[0], st[1], st[2], st[3], st[4], st[5], st[6]);
+            // not a k-mer start, or (sharded index) a key another device owns: no lookup, the position reads as absent
+            const bool own = p.tab.n_shards <= 1 || kh_shard_of(key, p.tab.n_shards) == p.tab.shard;
+            key = (((~mask >> lane) & 1ull) && own) ? key : KH_NO_KEY;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            c_lookup += key != KH_NO_KEY ? 1u : 0u;
+        }
+        srec[lane] = make_uint4(0, 0, 0, 0);  // absent unless a matching cell says otherwise
+        // leave the bitmap clean for the next batch (a ring iteration stores into the slack word behind the bitmap)
+        if (lane == 0) p.invalid[ring ? n_win + 1 : w] = 0ull;
+        c_probe += key != KH_NO_KEY ? 1u : 0u;
+
+        // ---- issue: TWO lanes read one bucket, PIECES 16-byte cells each, 32 buckets per round, two rounds
+        uint4 ld[2][PIECES];
+        uint32_t rk[2], ro[2], rs[2];
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int src_lane = 32 * r + (int)pair;  // round r serves the keys of lanes 32r .. 32r+31
+            rk[r] = __shfl(key, src_lane, 64);
+            ro[r] = __shfl(off, src_lane, 64);
+            rs[r] = __shfl(step, src_lane, 64);
+            uint32_t bucket = 0u;
+            if (rk[r] != KH_NO_KEY) {
+                bucket = table_home_bucket(p.tab, rk[r]) + rs[r];
+                bucket = bucket >= n_buckets ? bucket - n_buckets : bucket;
+            }
+            const uint4 *src = p.tab.cells + (uint64_t)bucket * KH_CELLS_PER_BUCKET + sub;
+#pragma unroll
+            for (int i = 0; i < PIECES; i++) ld[r][i] = load_cell(src + 2 * i, p.tab.nontemporal);
+        }
+        // ---- the next regular window's inputs (a ring iteration fetches the pending window's again)
+        if (!ring) w += stride;
+        fetch(w, mask, ra, rb);
+        // ---- consume
+        uint4 *const recw = p.rec + base, *const rec2w = p.rec2 + base;  // scalar bases, 32-bit lane offsets
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const uint8_t *st = stage + lane;
-        uint32_t key = kh_key_from_codes(st[0], st[1], st[2], st[3], st[4], st[5], st[6]);
-        // not a k-mer start, or (sharded index) a key another device owns: no lookup, the position reads as absent
-        const bool own = p.tab.n_shards <= 1 || kh_shard_of(key, p.tab.n_shards) == p.tab.shard;
-        key = (((valid >> lane) & 1ull) && own) ? key : KH_NO_KEY;
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            // my matching cell, if any (a key is in at most one cell); selects on VALUES, constant indices only
+            uint32_t mi = (uint32_t)PIECES, my = 0, mz = 0, mw = 0;
+#pragma unroll
+            for (int i = PIECES - 1; i >= 0; i--) {
+                const uint4 l = ld[r][i];
+                const bool mm = l.x == rk[r];
+                mi = sel(mm, (uint32_t)i, mi); my = sel(mm, l.y, my); mz = sel(mm, l.z, mz); mw = sel(mm, l.w, mw);
+            }
+            const bool m = mi < (uint32_t)PIECES;
+            // the other lane of the pair: did it match, and in which of its cells (quad_perm [1,0,3,2])
+            const uint32_t pmi = (uint32_t)__builtin_amdgcn_update_dpp(PIECES, (int)mi, 0xB1, 0xf, 0xf, false);
+#if defined(KAAMER_ABL) && (KAAMER_ABL & 8)
+            if (m) c_found += (my ^ mz ^ mw) == 0x1234567u ? 2u : 1u;  // ablation: no record stores
+#else
+            if (m) srec[32 * r + (int)pair] = make_uint4(p.epoch, my, mz, mw);
+            c_found += m ? 1u : 0u;
+#endif
+            // the cell after the partner's matching cell is mine: partner cell (1-s) + 2 pmi -> my piece pmi + (1-s)
+            const uint32_t k = pmi + 1u - sub;
+            uint32_t cx = 0, cy = 0, cz = 0, cw = 0;
+#pragma unroll
+            for (int i = 0; i < PIECES; i++) {
+                const uint4 l = ld[r][i];
+                const bool kk = k == (uint32_t)i;
+                cx = sel(kk, l.x, cx); cy = sel(kk, l.y, cy); cz = sel(kk, l.z, cz); cw = sel(kk, l.w, cw);
+            }
+#if !(defined(KAAMER_ABL) && (KAAMER_ABL & 8))
+            if (cx == KH_CONT_KEY && pmi < (uint32_t)PIECES) rec2w[ro[r]] = make_uint4(cx, cy, cz, cw);
+#endif
+            // the key is in neither half of this bucket, and the bucket has no free cell (its last cell, held by the odd
+            // lane, is in use): the lookup goes on one bucket further, from the ring
+            const bool wk = sub == 1u && !m && pmi >= (uint32_t)PIECES && ld[r][PIECES - 1].x != KH_EMPTY_KEY && rk[r] != KH_NO_KEY &&
+                            rs[r] + 1u < n_buckets;
+            const unsigned long long W = __ballot(wk);
+            if (W) {  // wave-uniform; LDS only
+                if (wk) {
+                    const uint32_t slot = (ring_head + ring_n + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(W >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)W, 0u))) & (P_RING - 1u);
+                    ring_key[slot] = rk[r];
+                    ring_pos[slot] = (uint32_t)base + ro[r];  // positions fit 32 bits (checked on the host)
+                    ring_step[slot] = rs[r] + 1u;
+                }
+                ring_n += (uint32_t)__popcll(W);
+            }
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        c_lookup += key != KH_NO_KEY ? 1u : 0u;
-        Buckets q;
-        issue_window(std::integral_constant<uint32_t, 0u>(), key, 0u, q);
-        fetch(w + stride, mask, ra, rb);      // lands while the buckets are fetched and consumed
-        consume_window(std::integral_constant<uint32_t, 0u>(), base, q);
-        if (ring_n >= 64u) drain_ring();
+#if !(defined(KAAMER_ABL) && (KAAMER_ABL & 8))
+        {   // every lane stores the record of its own position: all 64 of a regular window (1 KB, contiguous), the found
+            // ones of a ring iteration (whose positions the regular pass has already marked absent)
+            const uint4 v = srec[lane];
+            if (!ring || v.x == p.epoch) recw[off] = v;
+        }
+#endif
     }
-    while (ring_n) drain_ring();
     const uint32_t t_lookup = wave_total(c_lookup), t_probe = wave_total(c_probe), t_found = wave_total(c_found);
     if (lane == 0) {
         const uint32_t rep = blockIdx.x * P_WAVES + wv;
