@@ -35,7 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-BUCKET_BYTES = 64      # kaamer_layout.h: 4 cells of 16 B
+BUCKET_BYTES = 64      # kaamer_layout.h: 8 slots of {u32 key, u32 val}
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 
 
@@ -117,7 +117,7 @@ def main():
                     help="batches pushed back to back in one step (default 200 protein batches / 3 read batches: ~25 ms)")
     ap.add_argument("--distinct-batches", type=int, default=8,
                     help="different pre-generated batches the steps rotate over (their bucket footprint exceeds the Infinity Cache)")
-    ap.add_argument("--load-factor", type=float, default=0.0, help="cells in use / cells of the table (0 = the library's default)")
+    ap.add_argument("--load-factor", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--check", type=int, default=50, help="queries checked against the oracle after timing")
@@ -278,25 +278,26 @@ def main():
     lookups_total = float(lk[0].item())
     queries_total = float(lk[1].item())
 
-    # ---- roofline, HBM bound (DESIGN.md "Measurement"); per LAUNCH (= one batch), from exact kernel-side counters:
-    #   search_group_kernel (the dominant kernel: probe + count in one launch)
-    #       1 B per residue position + 128 B per bucket inspected (8 cells x 16 B: keys AND their short
-    #       postings lists) + 4 B per protein id read from the arena (lists of more than 6 ids)
-    #       + 28 B per query (descriptor 16 + table offset 8 + hit count 4) + 8 B per query written (list offset)
-    #       + 8 or 12 B per emitted hit (pid, Kmatch[, first position])
-    #   rest of the step: prep (8 B offsets + 40 B meta + 24 B descriptor/offset per query, 1 B per sequence end),
-    #       translation for nucleotide input (1 B per nucleotide read twice: COUNT + WRITE; ORF residues, starts
-    #       and 40 B of meta written per ORF), G tier (rare)
+    # ---- roofline, HBM bound (DESIGN.md "Measurement"); per BATCH, from exact kernel-side counters:
+    #   probe_kernel : 1 B per residue position + 1 bit per position (k-mer-start bitmap)
+    #                  + 64 B per bucket inspected + 4 B per position (the val it writes)
+    #   count kernels: 4 B per position (val read back) + 4 B per arena word that must be read (list header + ids)
+    #                  + 28 B per query read (descriptor 16 + table offset 8 + hit count 4) + 8 B per query written
+    #                  + 8 or 12 B per emitted hit (pid, Kmatch[, first position])
+    #   rest of the batch: prep (8 B offsets + 40 B meta + 24 B descriptor/offset per query), translation for nucleotide
+    #                  input (1 B per nucleotide read twice: COUNT + WRITE; ORF residues and 40 B of meta per ORF)
     c = avg
     hit_b = 12 if (nucl or sharded_mode) else 8
-    search_bytes = c["n_in"] + BUCKET_BYTES * c["n_probe"] + 4 * c["n_list_ids"] + 36 * c["n_queries"] + hit_b * c["n_hits"]
+    n_pos = c["n_in"] if nucl else float(np.mean([len(q[0]) for q in batches]))  # positions kernel P walks
+    probe_bytes = n_pos + n_pos / 8 + BUCKET_BYTES * c["n_probe"] + 4 * n_pos
+    count_bytes = 4 * n_pos + 4 * (c["n_lists"] + c["n_list_ids"]) + 36 * c["n_queries"] + hit_b * c["n_hits"]
     if nucl:
         nt = float(np.mean([len(q[0]) for q in batches]))
         rest_bytes = 2 * nt + 48 * args.queries + c["n_in"] + 64 * c["n_queries"]
     else:
         rest_bytes = 9 * args.queries + 72 * c["n_queries"]
-    search_s = tm["probe_ms"] / n_calls / 1e3
-    tail_s = tm["count_ms"] / n_calls / 1e3
+    probe_s = tm["probe_ms"] / n_calls / 1e3
+    count_s = tm["count_ms"] / n_calls / 1e3
     step_s = elapsed / n_timed  # per batch, wall clock of the timed region
     # HBM traffic from the PMC counters is collected in separate rocprofv3 passes (profiles/); reported here only
     # when this run is the workload those passes measured
@@ -305,30 +306,34 @@ def main():
         pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
         for e in pm["runs"]:
             if (e["db_proteins"], e["queries"], e["workload"], e["db"]) == (args.db_proteins, args.queries, args.workload, args.db):
-                traffic = e["search_group_kernel"]["traffic_bytes_per_launch"]
+                traffic = e["traffic_bytes_per_batch"]
     except Exception:
         pass
-    whole_bytes = search_bytes + rest_bytes
+    whole_bytes = probe_bytes + count_bytes + rest_bytes
+
+    def kern(name, secs, nbytes, extra=None):
+        d = {"name": name, "ms": secs * 1e3, "algorithmic_bytes_per_launch": nbytes,
+             "achieved": nbytes / secs / 1e9 if secs > 0 else 0.0,
+             "frac": nbytes / secs / 1e9 / HBM_PEAK_GBPS if secs > 0 else 0.0,
+             "share_of_batch_time": secs / step_s if step_s > 0 else 0.0}
+        d.update(extra or {})
+        return d
+    kernels = [kern("probe_kernel", probe_s, probe_bytes,
+                    {"G_random_requests_per_s": c["n_probe"] / probe_s / 1e9 if probe_s > 0 else 0.0,
+                     "random_request_ceiling_G_per_s": 53.0}),  # tools/random_read_bench.hip: 16..128-byte records alike
+               kern("count_group_kernel (+ G tier, finalize)", count_s, count_bytes)]
+    kernels.sort(key=lambda k: -k["ms"])
     roofline = {
         "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
-        # the WHOLE step: all algorithmic bytes of a batch / wall time per batch of the timed region
+        # the WHOLE batch: all algorithmic bytes of a batch / wall time per batch of the timed region
         "achieved": whole_bytes / step_s / 1e9, "frac": whole_bytes / step_s / 1e9 / HBM_PEAK_GBPS,
         "traffic": traffic,
-        "scope": "whole batch (prep + search kernel + G tier), wall clock of the timed region",
+        "scope": "whole batch (prep [+ translation] + probe + count + G tier), wall clock of the timed region",
         "algorithmic_bytes_per_batch": whole_bytes,
         "bytes_per_lookup": whole_bytes / max(c["n_lookup"], 1),
-        "dominant_kernel": {
-            "name": "search_group_kernel (probe + count)", "ms": search_s * 1e3, "timed_launches": n_calls,
-            "algorithmic_bytes_per_launch": search_bytes,
-            "achieved": search_bytes / search_s / 1e9 if search_s > 0 else 0.0,
-            "frac": search_bytes / search_s / 1e9 / HBM_PEAK_GBPS if search_s > 0 else 0.0,
-            "share_of_batch_time": search_s / step_s if step_s > 0 else 0.0,
-            "G_random_requests_per_s": (c["n_probe"] + c["n_lists"]) / search_s / 1e9 if search_s > 0 else 0.0,
-            "random_request_ceiling_G_per_s": 53.0,  # tools/random_read_bench.hip: 16..128-byte records alike
-        },
-        "other_kernels_ms": tail_s * 1e3,
+        "dominant_kernel": kernels[0], "other_kernels": kernels[1:], "timed_launches": n_calls,
         "hip_event_batch_ms": tm["total_ms"] / n_calls,
-        "min_bytes_8B_slot": c["n_in"] + 8 * c["n_lookup"] + 4 * c["n_post"] + hit_b * c["n_hits"],
+        "min_bytes_8B_slot": n_pos + n_pos / 8 + 8 * c["n_lookup"] + 4 * n_pos + count_bytes,
     }
 
     cfg_workload = {"protein": "configs[1]: batches of %d protein queries per GPU vs ",

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define KAAMER_ABI_VERSION 2
+#define KAAMER_ABI_VERSION 1
 #define KAAMER_KMER_SIZE 7 /* pkg/search/search.go:45, pkg/makedb/makedb.go:30 */
 
 typedef enum {
@@ -69,17 +69,15 @@ typedef struct kaamer_image kaamer_image;
 typedef struct {
     uint64_t n_pairs;      /* unique (key,id) pairs in this shard              */
     uint64_t n_keys;       /* distinct keys in this shard                      */
-    uint64_t n_buckets;    /* 128-byte buckets of 8 cells                      */
+    uint64_t n_buckets;    /* 64-byte buckets                                  */
     uint64_t arena_words;  /* u32 words of the postings arena                  */
-    uint64_t n_inline;     /* keys whose whole list (<= 6 ids) is in the bucket */
-    uint64_t n_lists;      /* distinct lists in the arena (shared between keys) */
+    uint64_t n_inline;     /* keys whose single id is stored in the slot       */
+    uint64_t n_lists;      /* distinct postings lists in the arena             */
     uint64_t max_list;     /* longest postings list                            */
     uint64_t n_displaced;  /* keys not in their home bucket                    */
     uint32_t shard, n_shards;
     uint32_t max_protein_id;
     uint32_t reserved;
-    uint64_t n_cont;       /* keys whose list takes a second (continuation) cell */
-    uint64_t n_arena_keys; /* keys whose list lives in the arena               */
 } kaamer_image_stats;
 
 /* shard s of n_shards holds the keys with kaamer_shard_of(key) == s */

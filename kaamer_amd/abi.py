@@ -27,8 +27,7 @@ class ImageStats(C.Structure):
     _fields_ = [("n_pairs", C.c_uint64), ("n_keys", C.c_uint64), ("n_buckets", C.c_uint64),
                 ("arena_words", C.c_uint64), ("n_inline", C.c_uint64), ("n_lists", C.c_uint64),
                 ("max_list", C.c_uint64), ("n_displaced", C.c_uint64), ("shard", C.c_uint32),
-                ("n_shards", C.c_uint32), ("max_protein_id", C.c_uint32), ("reserved", C.c_uint32),
-                ("n_cont", C.c_uint64), ("n_arena_keys", C.c_uint64)]
+                ("n_shards", C.c_uint32), ("max_protein_id", C.c_uint32), ("reserved", C.c_uint32)]
 
     def as_dict(self):
         return {k: int(getattr(self, k)) for k, _ in self._fields_ if k != "reserved"}

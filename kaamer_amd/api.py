@@ -27,7 +27,7 @@ class Image:
         self._h = C.c_void_p(handle)
 
     @classmethod
-    def from_pairs(cls, keys, ids, shard=0, n_shards=1, load_factor=0.0):
+    def from_pairs(cls, keys, ids, shard=0, n_shards=1, load_factor=0.5):
         keys = np.ascontiguousarray(keys, dtype=np.uint32)
         ids = np.ascontiguousarray(ids, dtype=np.uint32)
         pairs = np.empty((len(keys), 2), dtype=np.uint32)
@@ -39,7 +39,7 @@ class Image:
         return cls(h.value)
 
     @classmethod
-    def from_proteins(cls, seqs=None, ids=None, packed=None, shard=0, n_shards=1, load_factor=0.0):
+    def from_proteins(cls, seqs=None, ids=None, packed=None, shard=0, n_shards=1, load_factor=0.5):
         buf, offs = packed if packed is not None else pack_sequences(seqs)
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
         offs = np.ascontiguousarray(offs, dtype=np.uint64)

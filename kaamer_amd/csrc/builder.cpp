@@ -102,26 +102,14 @@ int kaamer_image_alloc(kaamer_image *img, uint64_t n_buckets, uint64_t arena_wor
 static int build_from_sorted_input(uint64_t *pairs64, uint64_t n, uint32_t shard, uint32_t n_shards,
                                    double load, kaamer_image **out)
 {
-    // default: 1.5 cells in use per 4-cell bucket -- 6.6 % of the buckets are full, 2 % of the keys displaced
-    // (Poisson), i.e. about 3 % of the lookups need a second bucket
-    if (!(load > 0.05 && load <= 0.95)) load = KH_CELLS_PER_BUCKET == 4 ? 0.375 : 0.5;
+    if (!(load > 0.05 && load <= 0.95)) load = 0.5;
     sort_u64(pairs64, n);
     n = (uint64_t)(std::unique(pairs64, pairs64 + n) - pairs64);
 
-    // one scan: distinct keys, extra cells (continuations), upper bound of the arena (no sharing)
-    uint64_t n_keys = 0, n_extra_cells = 0, ub_words = 4, n_lists_ub = 0;  // arena offset 0 is reserved
-    for (uint64_t i = 0; i < n;) {
-        uint64_t j = i + 1;
-        while (j < n && (pairs64[j] >> 32) == (pairs64[i] >> 32)) j++;
-        const uint64_t c = j - i;
-        n_keys++;
-        if (c > KH_INLINE_IDS) {
-            if (c <= KH_CELL_IDS_MAX) n_extra_cells++;
-            ub_words += ((c - 1 + 3) / 4) * 4;  // in case it ends up in the arena (ids 1..c-1)
-            n_lists_ub++;
-        }
-        i = j;
-    }
+    // distinct keys
+    uint64_t n_keys = 0;
+    for (uint64_t i = 0; i < n; i++)
+        if (i == 0 || (pairs64[i] >> 32) != (pairs64[i - 1] >> 32)) n_keys++;
 
     kaamer_image *img = new (std::nothrow) kaamer_image();
     if (!img) return kaamer_fail(KAAMER_E_NOMEM, "image alloc");
@@ -135,84 +123,103 @@ static int build_from_sorted_input(uint64_t *pairs64, uint64_t n, uint32_t shard
     img->hdr.n_pairs = n;
     img->hdr.n_keys = n_keys;
 
-    // load factor = cells in use / cells (continuation cells count)
-    uint64_t n_buckets = (uint64_t)((double)(n_keys + n_extra_cells) / (KH_CELLS_PER_BUCKET * load)) + 1;
+    uint64_t n_buckets = (uint64_t)((double)n_keys / (KH_SLOTS_PER_BUCKET * load)) + 1;
     if (n_buckets >= (1ull << 32)) { delete img; return kaamer_fail(KAAMER_E_ARG, "too many buckets"); }
-    if (ub_words / 4 >= KH_ARENA_BIT) { delete img; return kaamer_fail(KAAMER_E_ARG, "arena exceeds 32 GiB per shard"); }
+
+    // ---- postings arena with set sharing ------------------------------------
+    // pass 1: upper bound of arena words (no sharing) to size the buffer
+    uint64_t ub_words = 4;  // offset 0 is reserved (val 0 never used)
+    {
+        uint64_t i = 0;
+        while (i < n) {
+            uint64_t j = i + 1;
+            while (j < n && (pairs64[j] >> 32) == (pairs64[i] >> 32)) j++;
+            uint64_t c = j - i;
+            if (!(c == 1 && (uint32_t)pairs64[i] < KH_INLINE_BIT)) ub_words += ((1 + c + 3) / 4) * 4;
+            i = j;
+        }
+    }
+    if (ub_words / 4 >= KH_INLINE_BIT) { delete img; return kaamer_fail(KAAMER_E_ARG, "arena exceeds 32 GiB per shard"); }
     int rc = kaamer_image_alloc(img, n_buckets, ub_words);
     if (rc) { kaamer_image_free(img); return kaamer_fail(rc, "image buffers"); }
     memset(img->buckets, 0xFF, (size_t)n_buckets * sizeof(kh_bucket));
     memset(img->arena, 0, 16);
-    std::vector<uint8_t> fill((size_t)n_buckets, 0);  // cells in use per bucket
 
-    // dedupe table of arena lists: open addressing on the 64-bit content hash -> arena offset (16-B units)
+    // dedupe table: open addressing on the 64-bit content hash -> arena offset (16-B units)
+    uint64_t n_lists_ub = 0;
+    {
+        uint64_t i = 0;
+        while (i < n) {
+            uint64_t j = i + 1;
+            while (j < n && (pairs64[j] >> 32) == (pairs64[i] >> 32)) j++;
+            if (!(j - i == 1 && (uint32_t)pairs64[i] < KH_INLINE_BIT)) n_lists_ub++;
+            i = j;
+        }
+    }
     uint64_t dcap = 16;
     while (dcap < n_lists_ub * 2) dcap <<= 1;
     std::vector<uint64_t> dh(dcap, 0);
-    std::vector<uint32_t> doff(dcap, 0), dlen(dcap, 0);
+    std::vector<uint32_t> doff(dcap, 0);
 
-    uint64_t words = 4, n_inline = 0, n_lists = 0, max_list = 0, n_displaced = 0, n_cont = 0, n_arena_keys = 0;
+    uint64_t words = 4, n_inline = 0, n_lists = 0, max_list = 0, n_displaced = 0;
     uint32_t max_pid = 0;
     std::vector<uint32_t> tmp;
-    for (uint64_t i = 0; i < n;) {
+    uint64_t i = 0;
+    while (i < n) {
         uint64_t j = i + 1;
         while (j < n && (pairs64[j] >> 32) == (pairs64[i] >> 32)) j++;
-        const uint32_t key = (uint32_t)(pairs64[i] >> 32);
-        const uint32_t c = (uint32_t)(j - i);
+        uint32_t key = (uint32_t)(pairs64[i] >> 32);
+        uint32_t c = (uint32_t)(j - i);
+        uint32_t val;
         max_pid = std::max(max_pid, (uint32_t)pairs64[j - 1]);
-        max_list = std::max<uint64_t>(max_list, c);
-        // ---- the bucket: first one along the probe sequence with a free cell
-        uint64_t b = kh_home_bucket(key, n_shards, n_buckets);
-        bool home = true;
-        uint64_t tries = 0;
-        while (fill[b] == KH_CELLS_PER_BUCKET) {
-            if (++tries >= n_buckets) { kaamer_image_free(img); return kaamer_fail(KAAMER_E_CAPACITY, "table full"); }
-            b = (b + 1 == n_buckets) ? 0 : b + 1;
-            home = false;
-        }
-        if (!home) n_displaced++;
-        kh_cell *cell = &img->buckets[b].c[fill[b]];
-        const uint32_t free_cells = KH_CELLS_PER_BUCKET - fill[b];
-        auto id = [&](uint32_t t) { return t < c ? (uint32_t)pairs64[i + t] : (uint32_t)KH_NO_ID; };  // ascending
-        cell->key = key;
-        if (c <= KH_INLINE_IDS) {
-            cell->w1 = id(0); cell->w2 = id(1); cell->w3 = id(2);
-            fill[b] += 1;
+        if (c == 1 && (uint32_t)pairs64[i] < KH_INLINE_BIT) {
+            val = KH_INLINE_BIT | (uint32_t)pairs64[i];
             n_inline++;
-        } else if (c <= KH_CELL_IDS_MAX && free_cells >= 2) {
-            cell->w1 = id(0); cell->w2 = id(1); cell->w3 = id(2) | KH_CONT_BIT;
-            cell[1].key = KH_CONT_KEY;
-            cell[1].w1 = id(3); cell[1].w2 = id(4); cell[1].w3 = id(5);
-            fill[b] += 2;
-            n_inline++;
-            n_cont++;
         } else {
-            // arena: ids 1..c-1, shared between keys whose tails are identical
-            const uint32_t t = c - 1;
-            tmp.resize(t);
-            for (uint32_t k = 0; k < t; k++) tmp[k] = (uint32_t)pairs64[i + 1 + k];
-            const uint64_t h = hash_list(tmp.data(), t);
+            tmp.resize(c);
+            for (uint32_t t = 0; t < c; t++) tmp[t] = (uint32_t)pairs64[i + t];  // ascending
+            uint64_t h = hash_list(tmp.data(), c);
             uint64_t s = h & (dcap - 1);
-            uint32_t off = 0;
+            val = 0;
             for (;;) {
                 if (dh[s] == 0) break;
-                if (dh[s] == h && dlen[s] == t && memcmp(img->arena + (uint64_t)doff[s] * 4, tmp.data(), (size_t)t * 4) == 0) { off = doff[s]; break; }
+                if (dh[s] == h) {
+                    const uint32_t *l = img->arena + (uint64_t)doff[s] * 4;
+                    if (l[0] == c && memcmp(l + 1, tmp.data(), (size_t)c * 4) == 0) { val = doff[s]; break; }
+                }
                 s = (s + 1) & (dcap - 1);
             }
-            if (!off) {
-                off = (uint32_t)(words / 4);
+            if (!val) {
+                val = (uint32_t)(words / 4);
                 uint32_t *l = img->arena + words;
-                memcpy(l, tmp.data(), (size_t)t * 4);
-                const uint64_t padded = (((uint64_t)t + 3) / 4) * 4;
-                for (uint64_t q = t; q < padded; q++) l[q] = KH_NO_ID;
+                l[0] = c;
+                memcpy(l + 1, tmp.data(), (size_t)c * 4);
+                uint64_t used = 1 + (uint64_t)c, padded = ((used + 3) / 4) * 4;
+                for (uint64_t p = used; p < padded; p++) l[p] = KH_EMPTY_PID;
                 words += padded;
-                dh[s] = h; doff[s] = off; dlen[s] = t;
+                dh[s] = h;
+                doff[s] = val;
                 n_lists++;
+                max_list = std::max<uint64_t>(max_list, c);
             }
-            cell->w1 = KH_ARENA_BIT | off; cell->w2 = c; cell->w3 = id(0);
-            fill[b] += 1;
-            n_arena_keys++;
         }
+        // ---- insert into the bucket table ------------------------------------
+        uint64_t b = kh_home_bucket(key, n_shards, n_buckets);
+        bool placed = false, home = true;
+        for (uint64_t tries = 0; tries < n_buckets && !placed; tries++) {
+            kh_bucket &bk = img->buckets[b];
+            for (int sidx = 0; sidx < KH_SLOTS_PER_BUCKET; sidx++) {
+                if (bk.s[sidx].key == KH_EMPTY_KEY) {
+                    bk.s[sidx].key = key;
+                    bk.s[sidx].val = val;
+                    placed = true;
+                    break;
+                }
+            }
+            if (!placed) { b = (b + 1 == n_buckets) ? 0 : b + 1; home = false; }
+        }
+        if (!placed) { kaamer_image_free(img); return kaamer_fail(KAAMER_E_CAPACITY, "table full"); }
+        if (!home) n_displaced++;
         i = j;
     }
     img->hdr.arena_words = words;
@@ -221,8 +228,6 @@ static int build_from_sorted_input(uint64_t *pairs64, uint64_t n, uint32_t shard
     img->hdr.max_list = max_list;
     img->hdr.n_displaced = n_displaced;
     img->hdr.max_protein_id = max_pid;
-    img->hdr.n_cont = n_cont;
-    img->hdr.n_arena_keys = n_arena_keys;
     *out = img;
     return KAAMER_OK;
 }
@@ -250,9 +255,9 @@ int kaamer_image_build_pairs(const kaamer_pair *pairs, uint64_t n, uint32_t shar
     if (!p64) return kaamer_fail(KAAMER_E_NOMEM, "pairs buffer");
     uint64_t m = 0;
     for (uint64_t i = 0; i < n; i++) {
-        if (pairs[i].key >= KH_CONT_KEY || pairs[i].protein_id > KH_MAX_PID) {
+        if (pairs[i].key == KH_EMPTY_KEY || pairs[i].protein_id == KH_EMPTY_PID) {
             free(p64);
-            return kaamer_fail(KAAMER_E_ARG, "keys >= 0xFFFFFFFE and protein ids >= 0x7FFFFFFF are reserved");
+            return kaamer_fail(KAAMER_E_ARG, "key/id 0xFFFFFFFF is reserved");
         }
         if (n_shards > 1 && kh_shard_of(pairs[i].key, n_shards) != shard) continue;
         p64[m++] = ((uint64_t)pairs[i].key << 32) | pairs[i].protein_id;
@@ -292,7 +297,7 @@ int kaamer_image_build_proteins(const uint8_t *seqs, const uint64_t *offsets, co
     parallel_for(n_proteins, n_threads(), [&](size_t b, size_t e, unsigned) {
         for (size_t p = b; p < e; p++) {
             const uint32_t id = ids ? ids[p] : (uint32_t)p;  // inputTSV.go:141-142
-            if (id > KH_MAX_PID) { bad = 1; continue; }
+            if (id == KH_EMPTY_PID) { bad = 1; continue; }
             if (n_shards == 1) {
                 const uint64_t len = offsets[p + 1] - offsets[p];
                 woff[p + 1] = len >= KAAMER_KMER_SIZE ? len - KAAMER_KMER_SIZE + 1 : 0;
@@ -303,7 +308,7 @@ int kaamer_image_build_proteins(const uint8_t *seqs, const uint64_t *offsets, co
             }
         }
     });
-    if (bad) return kaamer_fail(KAAMER_E_ARG, "protein ids >= 0x7FFFFFFF are reserved");
+    if (bad) return kaamer_fail(KAAMER_E_ARG, "protein id 0xFFFFFFFF is reserved");
     for (uint32_t p = 0; p < n_proteins; p++) woff[p + 1] += woff[p];
     const uint64_t total = woff[n_proteins];
     uint64_t *p64 = (uint64_t *)malloc((total ? total : 1) * sizeof(uint64_t));
@@ -350,8 +355,8 @@ int kaamer_image_load(const char *path, kaamer_image **out)
     uint64_t nb = img->hdr.n_buckets, aw = img->hdr.arena_words;
     // the header drives allocations and device-side indexing: validate it against the file
     {
-        long here = ftell(f);
-        bool sane = nb >= 1 && nb < (1ull << 32) && aw >= 4 && aw / 4 < KH_ARENA_BIT && img->hdr.n_shards >= 1 &&
+        const long here = ftell(f);
+        bool sane = nb >= 1 && nb < (1ull << 32) && aw >= 4 && aw / 4 < KH_INLINE_BIT && img->hdr.n_shards >= 1 &&
                     img->hdr.shard < img->hdr.n_shards && here == (long)sizeof img->hdr;
         if (sane && fseek(f, 0, SEEK_END) == 0) {
             const long long size = ftell(f);
@@ -366,20 +371,20 @@ int kaamer_image_load(const char *path, kaamer_image **out)
     ok = ok && fread(img->arena, 4, (size_t)aw, f) == aw;
     fclose(f);
     if (!ok) { kaamer_image_free(img); return kaamer_fail(KAAMER_E_IO, "short read"); }
-    // every arena reference must stay inside the arena (a corrupted image must not make the kernels
-    // read outside the device allocation)
+    // every list reference must stay inside the arena (a corrupted image must not make the kernels read
+    // outside the device allocation)
     {
         std::atomic<int> bad_ref(0);
         parallel_for((size_t)nb, n_threads(), [&](size_t b0, size_t b1, unsigned) {
             for (size_t b = b0; b < b1; b++)
-                for (int c = 0; c < KH_CELLS_PER_BUCKET; c++) {
-                    const kh_cell &cl = img->buckets[b].c[c];
-                    if (cl.key >= KH_CONT_KEY || !(cl.w1 & KH_ARENA_BIT)) continue;
-                    const uint64_t off = cl.w1 & ~KH_ARENA_BIT;
-                    if (off == 0 || cl.w2 < 2 || off * 4 + (cl.w2 - 1) > aw) bad_ref = 1;
+                for (int c = 0; c < KH_SLOTS_PER_BUCKET; c++) {
+                    const kh_slot &sl = img->buckets[b].s[c];
+                    if (sl.key == KH_EMPTY_KEY || (sl.val & KH_INLINE_BIT)) continue;
+                    const uint64_t off = (uint64_t)sl.val * 4;
+                    if (sl.val == 0 || off + 1 > aw || off + 1 + img->arena[off] > aw) bad_ref = 1;
                 }
         });
-        if (bad_ref) { kaamer_image_free(img); return kaamer_fail(KAAMER_E_FORMAT, "index image: arena reference out of range"); }
+        if (bad_ref) { kaamer_image_free(img); return kaamer_fail(KAAMER_E_FORMAT, "index image: postings reference out of range"); }
     }
     *out = img;
     return KAAMER_OK;
@@ -392,7 +397,6 @@ static void fill_stats(const kh_image_header &h, kaamer_image_stats *s)
     s->arena_words = h.arena_words; s->n_inline = h.n_inline; s->n_lists = h.n_lists;
     s->max_list = h.max_list; s->n_displaced = h.n_displaced; s->shard = h.shard;
     s->n_shards = h.n_shards; s->max_protein_id = h.max_protein_id;
-    s->n_cont = h.n_cont; s->n_arena_keys = h.n_arena_keys;
 }
 
 int kaamer_image_get_stats(const kaamer_image *img, kaamer_image_stats *out)
@@ -414,33 +418,23 @@ void kaamer_image_free(kaamer_image *img)
 
 uint32_t kaamer_image_get(const kaamer_image *img, uint32_t key, uint32_t *ids, uint32_t cap)
 {
-    if (!img || img->hdr.n_buckets == 0 || key >= KH_CONT_KEY) return 0;
+    if (!img || img->hdr.n_buckets == 0) return 0;
     if (img->hdr.n_shards > 1 && kh_shard_of(key, img->hdr.n_shards) != img->hdr.shard) return 0;
     uint64_t nb = img->hdr.n_buckets, b = kh_home_bucket(key, img->hdr.n_shards, nb);
     for (uint64_t tries = 0; tries < nb; tries++) {
         const kh_bucket &bk = img->buckets[b];
-        for (int s = 0; s < KH_CELLS_PER_BUCKET; s++) {
-            const kh_cell &c = bk.c[s];
-            if (c.key != key) continue;
-            uint32_t n = 0;
-            auto put = [&](uint32_t id) { if (ids && n < cap) ids[n] = id; n++; };
-            if (c.w1 & KH_ARENA_BIT) {
-                const uint32_t *l = img->arena + (uint64_t)(c.w1 & ~KH_ARENA_BIT) * 4;
-                put(c.w3);
-                for (uint32_t t = 0; t + 1 < c.w2; t++) put(l[t]);
-                return n;
+        bool has_empty = false;
+        for (int s = 0; s < KH_SLOTS_PER_BUCKET; s++) {
+            if (bk.s[s].key == key) {
+                uint32_t v = bk.s[s].val;
+                if (v & KH_INLINE_BIT) { if (ids && cap) ids[0] = v & ~KH_INLINE_BIT; return 1; }
+                const uint32_t *l = img->arena + (uint64_t)v * 4;
+                for (uint32_t t = 0; t < l[0] && t < cap && ids; t++) ids[t] = l[1 + t];
+                return l[0];
             }
-            put(c.w1);
-            if (c.w2 != KH_NO_ID) put(c.w2);
-            if ((c.w3 & ~KH_CONT_BIT) != KH_NO_ID) put(c.w3 & ~KH_CONT_BIT);
-            if ((c.w3 & KH_CONT_BIT) && s + 1 < KH_CELLS_PER_BUCKET) {
-                const kh_cell &d = bk.c[s + 1];
-                const uint32_t w[3] = { d.w1, d.w2, d.w3 };
-                for (int t = 0; t < 3; t++) if (w[t] != KH_NO_ID) put(w[t]);
-            }
-            return n;
+            if (bk.s[s].key == KH_EMPTY_KEY) has_empty = true;
         }
-        if (bk.c[KH_CELLS_PER_BUCKET - 1].key == KH_EMPTY_KEY) return 0;  // a bucket with a free cell ends the probe sequence
+        if (has_empty) return 0;
         b = (b + 1 == nb) ? 0 : b + 1;
     }
     return 0;

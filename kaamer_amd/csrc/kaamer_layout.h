@@ -5,29 +5,19 @@
 // (kmer_store: key -> kcombId, kcomb_store: kcombId -> KComb{ProteinKeys};
 // pkg/kvstore/kv_stores.go:46-104, kcomb.proto) by
 //
-//   buckets : n_buckets x 128 B, each 8 CELLS of 16 B.  One random 128-byte request
-//             costs the memory system the same as a 64-byte one (tools/
-//             random_read_bench.hip: ~53e9 requests/s at either size), so a bucket
-//             carries its keys' SHORT POSTINGS LISTS inline: 8 lanes x 16 B read one
-//             bucket, the lane whose cell matches already holds the ids.
-//   arena   : u32 words; only lists too long for the bucket live here, as bare
-//             ids padded to 16 B and addressed in 16-B units; identical sets are
-//             stored once (the KComb sharing of kcomb_store.go:42-85).
+//   buckets : n_buckets x 64 B, each 8 slots of {u32 key, u32 val}
+//             (one HBM/fabric sector per probe; 4 lanes x 16 B read one bucket)
+//   arena   : u32 words; a postings list is {count, id0, id1, ...} padded to
+//             16 B and addressed in 16-B units; identical sets are stored once
+//             (the KComb sharing of kcomb_store.go:42-85)
 //
-// cell = {key, w1, w2, w3}:
-//   key = 0xFFFFFFFF             empty cell (cells of a bucket fill from 0 up, no deletions)
-//   key = 0xFFFFFFFE             CONTINUATION of the cell before it: w1..w3 = ids 3..5
-//   w1 bit31 = 0                 inline list: w1 = id0, w2 = id1, w3 = id2 (KH_NO_ID = unused);
-//                                w3 bit31 set: the next cell continues the list
-//   w1 bit31 = 1                 arena list: w1 & 0x7FFFFFFF = offset in 16-B units (never 0),
-//                                w2 = number of ids (>= 4), w3 = id0; the arena holds id1 ...
-// ids ascend inside a list; protein ids are < 0x7FFFFFFF.  The largest valid key is
-// 0xE773B9D4 ("YYYYYYY"), so both markers are outside the key space.
+// slot.val : bit31 = 1  -> the key has ONE protein id, stored inline (low 31 bits)
+//            bit31 = 0  -> offset of the postings list, in 16-B units (never 0)
+// slot.key : 0xFFFFFFFF = empty (the largest valid key is 0xE773B9D4, "YYYYYYY")
 //
-// Open addressing on buckets: a key lives in the first bucket along home, home+1, ...
-// (mod n_buckets) that had a free cell when it was inserted; a lookup stops at the
-// first bucket whose last cell is empty.  A list of 4..6 ids takes two cells when
-// that bucket has two free, otherwise one cell and the arena.
+// Open addressing: a key lives in the first bucket with a free slot along
+// home, home+1, ... (mod n_buckets); a lookup stops at the first bucket that
+// has an empty slot.  No deletions.
 #pragma once
 #include <stdint.h>
 
@@ -38,23 +28,15 @@
 #endif
 
 #define KH_EMPTY_KEY 0xFFFFFFFFu
-#define KH_CONT_KEY 0xFFFFFFFEu
-#define KH_EMPTY_PID 0xFFFFFFFFu   /* "no id" of the counting tables and result arrays */
-#define KH_NO_ID 0x7FFFFFFFu       /* unused id word of a cell */
-#define KH_MAX_PID 0x7FFFFFFEu
-#ifndef KH_CELLS_PER_BUCKET
-#define KH_CELLS_PER_BUCKET 4
-#endif
-#define KH_BUCKET_BYTES (16 * KH_CELLS_PER_BUCKET)
-#define KH_ARENA_BIT 0x80000000u   /* in w1 */
-#define KH_CONT_BIT 0x80000000u    /* in w3 of an inline head cell */
-#define KH_INLINE_IDS 3            /* ids in a head cell */
-#define KH_CELL_IDS_MAX 6          /* head + one continuation cell */
-#define KH_IMAGE_MAGIC 0x32544B4852454D41ull /* "AMERHKT2" little-endian tag */
-#define KH_IMAGE_VERSION (0x200 + KH_CELLS_PER_BUCKET)  /* layout 2, cells per bucket */
+#define KH_EMPTY_PID 0xFFFFFFFFu
+#define KH_SLOTS_PER_BUCKET 8
+#define KH_BUCKET_BYTES 64
+#define KH_INLINE_BIT 0x80000000u
+#define KH_IMAGE_MAGIC 0x31544B4852454D41ull /* "AMERHKT1" little-endian tag */
+#define KH_IMAGE_VERSION 1
 
-struct alignas(16) kh_cell { uint32_t key, w1, w2, w3; };
-struct alignas(KH_BUCKET_BYTES) kh_bucket { kh_cell c[KH_CELLS_PER_BUCKET]; };
+struct kh_slot { uint32_t key, val; };
+struct alignas(64) kh_bucket { kh_slot s[KH_SLOTS_PER_BUCKET]; };
 
 // murmur3 finalizer
 KH_HD uint32_t kh_mix32(uint32_t h)
@@ -95,7 +77,8 @@ KH_HD uint32_t kh_residue_code(uint8_t c)
     default: return KH_CODE_UNKNOWN;
     }
 }
-// (written as selects: the kernels evaluate this for every residue position, and exec-mask branches cost more than the arithmetic)
+// (written as selects: the kernels evaluate this for every residue position, and exec-mask
+// branches cost more than the arithmetic)
 KH_HD uint32_t kh_pair(uint32_t a, uint32_t b)
 {
     const uint32_t both = 22u + 21u * a + b;
@@ -121,8 +104,6 @@ struct kh_image_header {
     uint32_t max_protein_id;
     uint32_t pad0;
     double load_factor;
-    uint64_t n_cont;        /* keys whose list takes a continuation cell */
-    uint64_t n_arena_keys;  /* keys whose list lives in the arena */
-    uint8_t reserved[4096 - 120];
+    uint8_t reserved[4096 - 104];
 };
 static_assert(sizeof(kh_image_header) == 4096, "header is one page");

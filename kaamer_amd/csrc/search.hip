@@ -39,7 +39,6 @@
 #include <cstring>
 #include <mutex>
 #include <new>
-#include <type_traits>
 #include <vector>
 
 #include "kaamer_internal.h"
@@ -141,279 +140,140 @@ __device__ __forceinline__ void add_counter(unsigned long long *replicas, uint32
 }
 
 // ====================================================================================
-// The table as the kernels see it, and the lookup of one key
-// ====================================================================================
-// A lookup (replaces KmerStore.Get + KCombStore.Get, search.go:421-429) is ONE random 128-byte
-// request: the 8 cells of the key's home bucket.  In the counting kernel 8 adjacent lanes read
-// one bucket together (16 B each) and the lane whose cell matches already holds the key's first
-// three protein ids; a continuation cell (ids 3..5) sits in the next lane.  Only lists of more
-// than six ids need a second request (their tail lives in the arena).
-struct TableRef {
-    const uint4 *cells;   // n_buckets x KH_CELLS_PER_BUCKET cells of {key, w1, w2, w3}
-    const uint32_t *arena;
-    uint64_t n_buckets;
-    uint32_t n_shards, shard;
-    uint32_t nontemporal;  // bucket loads bypass the caches (a small batch against a large table reads a bucket once)
-};
-
-typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint4 load_cell(const uint4 *src, uint32_t nontemporal)
-{
-    const v4u *s = reinterpret_cast<const v4u *>(src);
-    const v4u t = nontemporal ? __builtin_nontemporal_load(s) : *s;
-    return make_uint4(t.x, t.y, t.z, t.w);
-}
-
-__device__ __forceinline__ uint32_t table_home_bucket(const TableRef &t, uint32_t key)
-{
-    // kh_home_bucket with 32-bit multiplies (n_buckets < 2^32)
-    const uint32_t rest = kh_mix32(key) * t.n_shards;
-    return __umulhi(rest, (uint32_t)t.n_buckets);
-}
-
-// c ? a : b on VALUES.  (`c ? x.y : z.y` on lvalues is an lvalue: clang selects between the two ADDRESSES and loads
-// once, which pins a register array in scratch memory.)
-__device__ __forceinline__ uint32_t sel(bool c, uint32_t a, uint32_t b) { return c ? a : b; }
-
-// One lane looks a key up on its own (rare paths: the key's home bucket is full and does not hold it;
-// the G tier).  Returns the number of ids (0 = absent); c0 = the matching cell, c1 = its continuation.
-struct LaneHit {
-    uint32_t cnt;
-    uint4 c0, c1;
-};
-__device__ __forceinline__ uint32_t cell_count(const uint4 &c0, const uint4 &c1)
-{
-    if (c0.y & KH_ARENA_BIT) return c0.z;
-    uint32_t n = 1u + (c0.z != KH_NO_ID ? 1u : 0u) + ((c0.w & ~KH_CONT_BIT) != KH_NO_ID ? 1u : 0u);
-    if (c0.w & KH_CONT_BIT) n += 1u + (c1.z != KH_NO_ID ? 1u : 0u) + (c1.w != KH_NO_ID ? 1u : 0u);
-    return n;
-}
-__device__ __forceinline__ LaneHit lane_lookup(const TableRef &tab, uint32_t key, uint32_t bucket, uint32_t &n_probe)
-{
-    LaneHit h;
-    h.cnt = 0;
-    h.c0 = h.c1 = make_uint4(KH_EMPTY_KEY, 0, 0, 0);
-    for (uint64_t tries = 0; tries < tab.n_buckets; tries++) {
-        n_probe++;
-        const uint4 *cells = tab.cells + (uint64_t)bucket * KH_CELLS_PER_BUCKET;
-        // the whole bucket in one go: independent loads, one memory round trip
-        uint4 c[KH_CELLS_PER_BUCKET];
-#pragma unroll
-        for (int i = 0; i < KH_CELLS_PER_BUCKET; i++) c[i] = cells[i];
-        // selects on values with constant indices (no early exit inside the unrolled loop): the cells stay in registers
-        bool found = false;
-        uint4 h0 = make_uint4(KH_EMPTY_KEY, 0, 0, 0), h1 = make_uint4(KH_EMPTY_KEY, 0, 0, 0);
-#pragma unroll
-        for (int i = KH_CELLS_PER_BUCKET - 1; i >= 0; i--) {
-            const bool mm = c[i].x == key;
-            found = found || mm;
-            h0.x = sel(mm, c[i].x, h0.x); h0.y = sel(mm, c[i].y, h0.y); h0.z = sel(mm, c[i].z, h0.z); h0.w = sel(mm, c[i].w, h0.w);
-            if (i + 1 < KH_CELLS_PER_BUCKET) {
-                h1.x = sel(mm, c[i + 1].x, h1.x); h1.y = sel(mm, c[i + 1].y, h1.y); h1.z = sel(mm, c[i + 1].z, h1.z); h1.w = sel(mm, c[i + 1].w, h1.w);
-            }
-        }
-        if (found) { h.c0 = h0; h.c1 = h1; h.cnt = cell_count(h0, h1); return h; }
-        if (c[KH_CELLS_PER_BUCKET - 1].x == KH_EMPTY_KEY) return h;  // a bucket with a free cell ends the probe sequence
-        bucket = bucket + 1u == (uint32_t)tab.n_buckets ? 0u : bucket + 1u;
-    }
-    return h;
-}
-
-// ====================================================================================
 // Kernel P — flat probe over residue positions
 // ====================================================================================
-// Position i of the residue buffer is a k-mer start iff bit (i & 63) of invalid[i >> 6] is clear
-// (prep sets the tail of every query and whole queries that are too short).  One wave handles 64
-// consecutive positions: residue codes are staged in LDS, each lane encodes its 7-mer
-// (k_store.go:91-117 in closed form), then the wave reads the 64 home buckets, TWO lanes per
-// 128-byte bucket, four 16-byte cells each (lane s of the pair: cells s, s+2, s+4, s+6), 32
-// buckets per round, two rounds (tools/bucket_read_bench.hip: 2, 4 or 8 lanes per bucket reach the
-// same request rate, one lane per bucket a quarter of it; per-round work costs instructions).  The
-// lane whose cell matches writes the position's RECORD for the counting kernel:
-//     rec[i]  = {epoch, w1, w2, w3}  the matching cell's list words (kaamer_layout.h); the batch's tag in the
-//                                    first word: a position whose record carries another tag is absent, so the
-//                                    kernel writes nothing for the lookups that find nothing
-//     rec2[i] = the continuation cell (ids 3..5), written by the other lane of the pair (only then)
-// so the counting kernel reads everything it needs with two coalesced 16-byte loads per position: the
-// random requests of a lookup (KmerStore.Get + KCombStore.Get, search.go:421-429) all happen here,
-// one per lookup, flat over the batch whatever the query lengths are.
+// Position i of the packed residue buffer is a k-mer start iff bit (i & 63) of
+// valid[i >> 6] is set (prep clears the tail of every query and whole queries that are
+// too short).  One wave handles 64 consecutive positions: residue codes are staged in
+// LDS, each lane encodes its 7-mer (k_store.go:91-117 in closed form), then the wave
+// probes the bucket table with 4 lanes per 64-byte bucket (16 B each, one fabric
+// sector per probe) and writes one u32 per position:
+//     vals[i] = 0            key absent (or position not a k-mer start)
+//             = slot.val     key present: inline protein id or postings-list offset
+// This replaces KmerStore.GetValueFromBadger (search.go:421) for the whole batch at
+// once; the work is perfectly balanced whatever the query lengths are.
 struct ProbeParams {
-    TableRef tab;
+    const uint4 *table;  // buckets viewed as 4 x uint4 each
+    uint64_t n_buckets;
+    uint32_t n_shards, shard;
     const uint8_t *residues;
-    unsigned long long *invalid;        // one bit per position, set = not a k-mer start; self-cleaning
+    unsigned long long *invalid;  // one bit per position, set = not a k-mer start; self-cleaning
     const unsigned long long *d_n_pos;  // device scalar: number of residue positions
-    uint4 *rec, *rec2;                  // one each per position
-    uint32_t epoch;                     // tag of this batch's records (never 0)
+    uint32_t *vals;
     unsigned long long *counters;
+    uint32_t nontemporal;  // bucket loads bypass the caches (small batch against a large table)
 };
 
 #define P_WAVES 4
-#define P_RING 128u  /* deferred lookups per wave (a power of two): fewer than 64 waiting + the 64 of a window */
 
-
-#define KH_NO_KEY 0xFFFFFFFDu  /* "no lookup for this position": equals no cell key (valid keys, 0xFFFFFFFF empty, 0xFFFFFFFE continuation) */
-
-__global__ __launch_bounds__(64 * P_WAVES, 6) void probe_kernel(ProbeParams p)
+__global__ __launch_bounds__(64 * P_WAVES) void probe_kernel(ProbeParams p)
 {
     __shared__ uint8_t s_lut[256];
     __shared__ uint8_t s_stage[P_WAVES][80];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));  // wave-uniform: window bases stay scalar
-    const uint32_t pair = lane >> 1, sub = lane & 1u;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const unsigned long long n_pos = *p.d_n_pos;
     const unsigned long long n_win = (n_pos + 63) >> 6;
     for (uint32_t i = tid; i < 256; i += 64 * P_WAVES) s_lut[i] = (uint8_t)kh_residue_code((uint8_t)i);
     __syncthreads();  // the only workgroup barrier: the waves run independently from here on
     uint32_t c_lookup = 0, c_probe = 0, c_found = 0;
     uint8_t *stage = s_stage[wv];
-    const uint32_t n_buckets = (uint32_t)p.tab.n_buckets;
-    // Lookups whose bucket is full and does not hold the key (a few per cent) go on in the NEXT bucket of the probe
-    // sequence.  Waiting for that second request inside the window would stall the whole wave in six windows out of seven,
-    // so such lookups are put on a ring in LDS (key, position, buckets walked) and looked up later, 64 at a time, as an
-    // iteration of their own through the same code.  The loop body is ONE straight line for both kinds of iteration and
-    // every global load and store in it is issued unconditionally (idle lanes and idle iterations touch harmless
-    // addresses): the compiler's s_waitcnt vmcnt(N) then counts exactly, and waiting for the prefetched inputs of the next
-    // window does not wait for this window's record stores.
-    __shared__ uint32_t s_ring[P_WAVES][3][P_RING];
-    // Records leave through LDS: the lane whose cell matches parks the record in the slot of the lane that asked, and
-    // every lane then stores its own position's record -- one coalesced 1 KB store per window instead of ~45 separate
-    // 16-byte stores.  (Measured: the scattered stores cost as many memory requests as the bucket reads themselves, and
-    // the memory system serves ~53e9 requests/s, loads and stores together.)
-    __shared__ uint4 s_rec[P_WAVES][64];
-    uint4 *const srec = s_rec[wv];
-    uint32_t *const ring_key = s_ring[wv][0], *const ring_pos = s_ring[wv][1], *const ring_step = s_ring[wv][2];
-    uint32_t ring_head = 0, ring_n = 0;  // wave-uniform
-    constexpr int PIECES = KH_CELLS_PER_BUCKET / 2;  // cells per lane: lane s of a pair holds cells s, s+2, ...
 
     const unsigned long long stride = (unsigned long long)gridDim.x * P_WAVES;
     unsigned long long w = (unsigned long long)blockIdx.x * P_WAVES + wv;
-    // the bitmap word and the residues of the NEXT window are loaded behind the bucket loads of the current one;
-    // windows and reads past the end are clamped (the positions involved are marked invalid or unused)
+    // software pipeline: the bitmap word and the residues of the NEXT window are in flight
+    // while the buckets of the current one are fetched
     unsigned long long mask = 0;
     uint32_t ra = 0, rb = 0;
     auto fetch = [&](unsigned long long win, unsigned long long &m, uint32_t &a, uint32_t &b) {
-        const unsigned long long wc = win < n_win ? win : n_win - 1;
-        m = p.invalid[wc];
-        const unsigned long long i0 = (wc << 6) + lane, last = n_pos - 1;
-        a = p.residues[i0 < last ? i0 : last];
-        b = p.residues[i0 + 64 < last ? i0 + 64 : last];  // lanes 0..5 hold the halo
+        m = 0; a = 0; b = 0;
+        if (win < n_win) {
+            m = ~p.invalid[win];
+            const unsigned long long i0 = (win << 6) + lane;
+            if (i0 < n_pos) a = p.residues[i0];
+            if (lane < 6 && i0 + 64 < n_pos) b = p.residues[i0 + 64];
+        }
     };
-    if (n_win) fetch(w, mask, ra, rb);
+    fetch(w, mask, ra, rb);
 
-    while (n_win) {
-        const bool ring = ring_n >= 64u || (w >= n_win && ring_n > 0u);  // wave-uniform: this iteration serves the ring
-        if (!ring && w >= n_win) break;
-        unsigned long long base = 0;
-        uint32_t key = KH_NO_KEY, off = 0, step = 0;
-        if (ring) {
-            const uint32_t n = ring_n < 64u ? ring_n : 64u;
-            if (lane < n) {
-                const uint32_t slot = (ring_head + lane) & (P_RING - 1u);
-                key = ring_key[slot]; off = ring_pos[slot]; step = ring_step[slot];
-            }
-            ring_head = (ring_head + n) & (P_RING - 1u);
-            ring_n -= n;
-        } else {
-            base = w << 6;
-            off = lane;
-            stage[lane] = s_lut[ra];
-            if (lane < 6) stage[64 + lane] = s_lut[rb];
+    for (; w < n_win; w += stride) {
+        const unsigned long long base = w << 6;
+        unsigned long long nmask;
+        uint32_t na, nb;
+        fetch(w + stride, nmask, na, nb);
+        if (lane == 0 && mask != ~0ull) p.invalid[w] = 0ull;  // leave the bitmap clean for the next batch
+
+        uint32_t key = KH_EMPTY_KEY;
+        if (mask) {
+            stage[lane] = (base + lane < n_pos) ? s_lut[ra] : (uint8_t)KH_CODE_UNKNOWN;
+            if (lane < 6) stage[64 + lane] = (base + 64 + lane < n_pos) ? s_lut[rb] : (uint8_t)KH_CODE_UNKNOWN;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const uint8_t *st = stage + lane;
-            key = kh_key_from_codes(st[0], st[1], st[2], st[3], st[4], st[5], st[6]);
-            // not a k-mer start, or (sharded index) a key another device owns: no lookup, the position reads as absent
-            const bool own = p.tab.n_shards <= 1 || kh_shard_of(key, p.tab.n_shards) == p.tab.shard;
-            key = (((~mask >> lane) & 1ull) && own) ? key : KH_NO_KEY;
+            if ((mask >> lane) & 1ull) {
+                const uint8_t *st = stage + lane;
+                key = kh_key_from_codes(st[0], st[1], st[2], st[3], st[4], st[5], st[6]);
+                // sharded index: this device probes only the keys it owns
+                if (p.n_shards > 1 && kh_shard_of(key, p.n_shards) != p.shard) key = KH_EMPTY_KEY;
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            c_lookup += key != KH_NO_KEY ? 1u : 0u;
         }
-        srec[lane] = make_uint4(0, 0, 0, 0);  // absent unless a matching cell says otherwise
-        // leave the bitmap clean for the next batch (a ring iteration stores into the slack word behind the bitmap)
-        if (lane == 0) p.invalid[ring ? n_win + 1 : w] = 0ull;
-        c_probe += key != KH_NO_KEY ? 1u : 0u;
+        const uint32_t bucket = (key != KH_EMPTY_KEY) ? (uint32_t)kh_home_bucket(key, p.n_shards, p.n_buckets) : 0u;
 
-        // ---- issue: TWO lanes read one bucket, PIECES 16-byte cells each, 32 buckets per round, two rounds
-        uint4 ld[2][PIECES];
-        uint32_t rk[2], ro[2], rs[2];
+        // round j serves the k-mers of lanes 16j..16j+15; lane 4g+j ends up owning k-mer 16j+g
+        uint4 ld[4];
+        uint32_t rkey[4], rbk[4];
 #pragma unroll
-        for (int r = 0; r < 2; r++) {
-            const int src_lane = 32 * r + (int)pair;  // round r serves the keys of lanes 32r .. 32r+31
-            rk[r] = __shfl(key, src_lane, 64);
-            ro[r] = __shfl(off, src_lane, 64);
-            rs[r] = __shfl(step, src_lane, 64);
-            uint32_t bucket = 0u;
-            if (rk[r] != KH_NO_KEY) {
-                bucket = table_home_bucket(p.tab, rk[r]) + rs[r];
-                bucket = bucket >= n_buckets ? bucket - n_buckets : bucket;
+        for (int j = 0; j < 4; j++) {
+            const int src = 16 * j + (int)(lane >> 2);
+            rbk[j] = __shfl(bucket, src, 64);
+            rkey[j] = __shfl(key, src, 64);
+            ld[j] = make_uint4(KH_EMPTY_KEY, 0, KH_EMPTY_KEY, 0);
+            // nontemporal when the batch is small against the table (a bucket is then read once per
+            // batch): keeping it out of the way of the lines the counting kernel re-reads (vals, list
+            // heads) is worth 8 us per 10 000-query batch downstream.  A 1 M-read batch touches every
+            // bucket several times and wants them cached (+9 % probe time when nontemporal).
+            if (rkey[j] != KH_EMPTY_KEY) {
+                typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+                const v4u *src = reinterpret_cast<const v4u *>(p.table) + (uint64_t)rbk[j] * 4 + (lane & 3u);
+                const v4u t = p.nontemporal ? __builtin_nontemporal_load(src) : *src;
+                ld[j] = make_uint4(t.x, t.y, t.z, t.w);
             }
-            const uint4 *src = p.tab.cells + (uint64_t)bucket * KH_CELLS_PER_BUCKET + sub;
-#pragma unroll
-            for (int i = 0; i < PIECES; i++) ld[r][i] = load_cell(src + 2 * i, p.tab.nontemporal);
         }
-        // ---- the next regular window's inputs (a ring iteration fetches the pending window's again)
-        if (!ring) w += stride;
-        fetch(w, mask, ra, rb);
-        // ---- consume
-        uint4 *const recw = p.rec + base, *const rec2w = p.rec2 + base;  // scalar bases, 32-bit lane offsets
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        uint32_t okey = KH_EMPTY_KEY, oval = 0, obucket = 0;
+        bool oempty = true;
 #pragma unroll
-        for (int r = 0; r < 2; r++) {
-            // my matching cell, if any (a key is in at most one cell); selects on VALUES, constant indices only
-            uint32_t mi = (uint32_t)PIECES, my = 0, mz = 0, mw = 0;
+        for (int j = 0; j < 4; j++) {
+            const uint32_t kk = rkey[j];
+            uint32_t r = (ld[j].x == kk) ? ld[j].y : ((ld[j].z == kk) ? ld[j].w : 0u);
+            uint32_t e = (ld[j].x == KH_EMPTY_KEY || ld[j].z == KH_EMPTY_KEY) ? 1u : 0u;
+            r |= __shfl_xor(r, 1, 64); e |= __shfl_xor(e, 1, 64);
+            r |= __shfl_xor(r, 2, 64); e |= __shfl_xor(e, 2, 64);
+            if ((lane & 3u) == (uint32_t)j) { okey = kk; oval = r; oempty = (e != 0u); obucket = rbk[j]; }
+        }
+        const bool valid = okey != KH_EMPTY_KEY;
+        if (valid) { c_lookup++; c_probe++; }
+        // rare: home bucket full and key not in it -> this lane walks the following buckets alone
+        if (valid && oval == 0u && !oempty) {
+            for (uint64_t tries = 1; tries < p.n_buckets; tries++) {
+                obucket = (obucket + 1u == (uint32_t)p.n_buckets) ? 0u : obucket + 1u;
+                c_probe++;
+                bool e = false;
 #pragma unroll
-            for (int i = PIECES - 1; i >= 0; i--) {
-                const uint4 l = ld[r][i];
-                const bool mm = l.x == rk[r];
-                mi = sel(mm, (uint32_t)i, mi); my = sel(mm, l.y, my); mz = sel(mm, l.z, mz); mw = sel(mm, l.w, mw);
-            }
-            const bool m = mi < (uint32_t)PIECES;
-            // the other lane of the pair: did it match, and in which of its cells (quad_perm [1,0,3,2])
-            const uint32_t pmi = (uint32_t)__builtin_amdgcn_update_dpp(PIECES, (int)mi, 0xB1, 0xf, 0xf, false);
-#if defined(KAAMER_ABL) && (KAAMER_ABL & 8)
-            if (m) c_found += (my ^ mz ^ mw) == 0x1234567u ? 2u : 1u;  // ablation: no record stores
-#else
-            if (m) srec[32 * r + (int)pair] = make_uint4(p.epoch, my, mz, mw);
-            c_found += m ? 1u : 0u;
-#endif
-            // the cell after the partner's matching cell is mine: partner cell (1-s) + 2 pmi -> my piece pmi + (1-s)
-            const uint32_t k = pmi + 1u - sub;
-            uint32_t cx = 0, cy = 0, cz = 0, cw = 0;
-#pragma unroll
-            for (int i = 0; i < PIECES; i++) {
-                const uint4 l = ld[r][i];
-                const bool kk = k == (uint32_t)i;
-                cx = sel(kk, l.x, cx); cy = sel(kk, l.y, cy); cz = sel(kk, l.z, cz); cw = sel(kk, l.w, cw);
-            }
-#if !(defined(KAAMER_ABL) && (KAAMER_ABL & 8))
-            if (cx == KH_CONT_KEY && pmi < (uint32_t)PIECES) rec2w[ro[r]] = make_uint4(cx, cy, cz, cw);
-#endif
-            // the key is in neither half of this bucket, and the bucket has no free cell (its last cell, held by the odd
-            // lane, is in use): the lookup goes on one bucket further, from the ring
-            const bool wk = sub == 1u && !m && pmi >= (uint32_t)PIECES && ld[r][PIECES - 1].x != KH_EMPTY_KEY && rk[r] != KH_NO_KEY &&
-                            rs[r] + 1u < n_buckets;
-            const unsigned long long W = __ballot(wk);
-            if (W) {  // wave-uniform; LDS only
-                if (wk) {
-                    const uint32_t slot = (ring_head + ring_n + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(W >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)W, 0u))) & (P_RING - 1u);
-                    ring_key[slot] = rk[r];
-                    ring_pos[slot] = (uint32_t)base + ro[r];  // positions fit 32 bits (checked on the host)
-                    ring_step[slot] = rs[r] + 1u;
+                for (int s = 0; s < 4; s++) {
+                    const uint4 v = p.table[(uint64_t)obucket * 4 + s];
+                    if (v.x == okey) oval = v.y;
+                    if (v.z == okey) oval = v.w;
+                    e = e || v.x == KH_EMPTY_KEY || v.z == KH_EMPTY_KEY;
                 }
-                ring_n += (uint32_t)__popcll(W);
+                if (oval != 0u || e) break;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-#if !(defined(KAAMER_ABL) && (KAAMER_ABL & 8))
-        {   // every lane stores the record of its own position: all 64 of a regular window (1 KB, contiguous), the found
-            // ones of a ring iteration (whose positions the regular pass has already marked absent)
-            const uint4 v = srec[lane];
-            if (!ring || v.x == p.epoch) recw[off] = v;
-        }
-#endif
+        if (valid && oval != 0u) c_found++;
+        // the owner lane writes the position it owns: 16*(lane&3) + (lane>>2)
+        const unsigned long long opos = base + 16u * (lane & 3u) + (lane >> 2);
+        if (opos < n_pos) p.vals[opos] = valid ? oval : 0u;
+
+        mask = nmask; ra = na; rb = nb;
     }
     const uint32_t t_lookup = wave_total(c_lookup), t_probe = wave_total(c_probe), t_found = wave_total(c_found);
     if (lane == 0) {
@@ -424,25 +284,13 @@ __global__ __launch_bounds__(64 * P_WAVES, 6) void probe_kernel(ProbeParams p)
     }
 }
 
-// a position's record -> number of ids (0 = absent) and whether the list lives in the arena
-__device__ __forceinline__ uint32_t rec_count(uint32_t epoch, const uint4 &h, const uint4 &c)
-{
-    // selects, not branches (evaluated for every position)
-    const bool arena = (h.y & KH_ARENA_BIT) != 0u, cont = (h.w & KH_CONT_BIT) != 0u;
-    const uint32_t head = 1u + (h.z != KH_NO_ID ? 1u : 0u) + ((h.w & ~KH_CONT_BIT) != KH_NO_ID ? 1u : 0u);
-    const uint32_t tail = 1u + (c.z != KH_NO_ID ? 1u : 0u) + (c.w != KH_NO_ID ? 1u : 0u);
-    const uint32_t n = arena ? h.z : head + (cont ? tail : 0u);
-    return h.x == epoch ? n : 0u;
-}
-
 // ====================================================================================
 // Kernel C — per-query counting (postings expansion + Counter increments)
 // ====================================================================================
 struct QInfo;
 struct CountParams {
     const uint32_t *arena;
-    const uint4 *rec, *rec2;  // from kernel P: one each per residue position
-    uint32_t epoch;           // rec[i].x == epoch: the position's key is present
+    const uint32_t *vals;  // from kernel P, indexed like the residue buffer
     // query groups (count_group.hip.inc)
     const struct QInfo *qinfo;
     const uint64_t *slot_off;   // exclusive scan of the table capacities
@@ -581,59 +429,127 @@ __device__ __forceinline__ bool add_runs(const Table &tab, uint32_t x, uint32_t 
     return ok;
 }
 
-// G tier: one 64-position window of ONE query per call: the counter increments (KCombStore.Get + the id
-// loop of search.go:427-436) from the probe's records: first ids with run merging, short lists lane by
-// lane, long lists (arena) spread over the whole wave.  No workgroup barriers inside.  COUNT_ONLY: only
-// sum the postings (G tier sizing pass).
-__device__ __forceinline__ uint32_t rec_id(const uint32_t *arena, const uint4 &h, const uint4 &c, uint32_t t)
-{
-    if (h.y & KH_ARENA_BIT) return t == 0u ? h.w : arena[(uint64_t)(h.y & ~KH_ARENA_BIT) * 4 + (t - 1u)];
-    switch (t) {
-    case 0: return h.y;
-    case 1: return h.z;
-    case 2: return h.w & ~KH_CONT_BIT;
-    case 3: return c.y;
-    case 4: return c.z;
-    default: return c.w;
-    }
-}
-template <class Table, bool COUNT_ONLY>
-__device__ __forceinline__ bool count_window(const CountParams &p, uint64_t aa_off, int32_t size, int32_t c0, const Table &tab,
-                                             PostCtr &c)
+// NWIN 64-position windows of one query, processed by one wave with all their memory
+// round trips overlapped: (1) the probe results of every window, (2) the 16-byte heads of
+// every postings list (count + first three ids), (3) the remaining ids of all lists,
+// spread evenly over the 64 lanes whatever the individual list lengths are (per-window
+// prefix sum of the leftovers, owner found by binary search in LDS), then the counter
+// increments (KCombStore.Get + the id loop of search.go:427-436).  Window k starts at
+// c0 + k*stride.  `s_pref` is 64 words of LDS private to the wave.  No workgroup
+// barriers inside.  COUNT_ONLY: only sum the postings (G tier sizing pass).
+template <class Table, int NWIN, bool COUNT_ONLY>
+__device__ __forceinline__ bool count_windows(const CountParams &p, const uint32_t *vals,
+                                              int32_t size, int32_t c0, int32_t stride, const Table &tab, PostCtr &c,
+                                              volatile uint32_t *s_pref)
 {
     const uint32_t lane = lane_id();
-    const int32_t pos = c0 + (int32_t)lane;
-    uint4 h = make_uint4(~p.epoch, 0, 0, 0), hc = make_uint4(0, 0, 0, 0);
-    if (pos < size) { h = p.rec[aa_off + (uint64_t)pos]; hc = p.rec2[aa_off + (uint64_t)pos]; }
-    const uint32_t cnt = rec_count(p.epoch, h, hc);
-    const bool arena = cnt != 0u && (h.y & KH_ARENA_BIT) != 0u;
-    if (cnt != 0u) {
-        c.post += cnt;
-        if (arena) { c.lists++; c.lids += cnt - 1u; }
+    uint32_t v[NWIN];
+    uint4 h[NWIN];
+#pragma unroll
+    for (int k = 0; k < NWIN; k++) {
+        const int32_t pos = c0 + k * stride + (int32_t)lane;
+        v[k] = 0u;
+        h[k] = make_uint4(0, 0, 0, 0);
+        if (pos < size) {
+            v[k] = vals[pos];
+            if (v[k] & KH_INLINE_BIT) h[k] = make_uint4(1u, v[k] & ~KH_INLINE_BIT, 0, 0);
+            else if (v[k] != 0u) h[k] = reinterpret_cast<const uint4 *>(p.arena)[v[k]];  // {count, id0, id1, id2}
+        }
     }
-    if (COUNT_ONLY) return true;
     bool ok = true;
     uint32_t nnew = 0;
-    ok = add_runs(tab, cnt != 0u ? rec_id(p.arena, h, hc, 0u) : KH_EMPTY_PID, (uint32_t)pos, nnew);
-    constexpr uint32_t SERIAL = 8;  // ids a lane adds on its own; the rest of a longer list is shared by the wave
-    const uint32_t n_ser = cnt < SERIAL ? cnt : SERIAL;
-    for (uint32_t t = 1; t < n_ser; t++) ok = tab.add_n(rec_id(p.arena, h, hc, t), (uint32_t)pos, 1u, nnew) && ok;
-    unsigned long long big = __ballot(cnt > SERIAL);
-    while (big) {
-        const int l = __ffsll((long long)big) - 1;
-        big &= big - 1ull;
-        const uint32_t cnt_l = __shfl(cnt, l, 64), off_l = __shfl(h.y & ~KH_ARENA_BIT, l, 64), pos_l = (uint32_t)c0 + (uint32_t)l;
-        for (uint32_t t = SERIAL + lane; t < cnt_l; t += 64)
-            ok = tab.add_n(p.arena[(uint64_t)off_l * 4 + (t - 1u)], pos_l, 1u, nnew) && ok;
+    // leftovers (ids beyond the three that came with the head): all their loads are issued
+    // before anything is consumed
+    constexpr int XIT = 2;  // leftover rounds kept in registers per window (64 ids each)
+    uint32_t xid[NWIN][XIT], xpos[NWIN][XIT];
+    uint32_t xtotal[NWIN];
+    if (!COUNT_ONLY) {
+#pragma unroll
+        for (int k = 0; k < NWIN; k++) {
+            const uint32_t lcnt = h[k].x;
+            const uint32_t extra = lcnt > 3u ? lcnt - 3u : 0u;
+            uint32_t inc = extra;  // inclusive prefix over the wave
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = __shfl_up(inc, o, 64);
+                if ((int)lane >= o) inc += t;
+            }
+            xtotal[k] = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+            s_pref[k * 64 + lane] = inc - extra;  // exclusive prefix
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < NWIN; k++) {
+            const volatile uint32_t *pref = s_pref + k * 64;
+#pragma unroll
+            for (int it = 0; it < XIT; it++) {
+                const uint32_t t = (uint32_t)it * 64u + lane;
+                const bool act = t < xtotal[k];
+                uint32_t lo = 0;
+                if (act) {  // largest lane with pref[lane] <= t owns leftover t
+#pragma unroll
+                    for (int sft = 32; sft > 0; sft >>= 1)
+                        if (pref[lo + sft] <= t) lo += sft;
+                }
+                // executed by all lanes: the owner may be a lane that is idle in this round
+                const uint32_t off = __shfl(v[k], (int)lo, 64);
+                xid[k][it] = KH_EMPTY_PID;
+                xpos[k][it] = (uint32_t)(c0 + k * stride) + lo;
+                if (act) xid[k][it] = p.arena[(uint64_t)off * 4 + 4 + (t - pref[lo])];
+            }
+        }
+        // very long lists (more than XIT*64 leftovers in one window): counted as they arrive
+#pragma unroll
+        for (int k = 0; k < NWIN; k++) {
+            const volatile uint32_t *pref = s_pref + k * 64;
+            for (uint32_t t0 = XIT * 64u; t0 < xtotal[k]; t0 += 64) {
+                const uint32_t t = t0 + lane;
+                const bool act = t < xtotal[k];
+                uint32_t lo = 0;
+                if (act) {
+#pragma unroll
+                    for (int sft = 32; sft > 0; sft >>= 1)
+                        if (pref[lo + sft] <= t) lo += sft;
+                }
+                const uint32_t off = __shfl(v[k], (int)lo, 64);
+                if (act) ok = ok && tab.add_n(p.arena[(uint64_t)off * 4 + 4 + (t - pref[lo])], (uint32_t)(c0 + k * stride) + lo, 1u, nnew);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
-    const uint32_t wave_new = wave_total(nnew);
-    if (lane == 0 && wave_new) atomicAdd(tab.nd, wave_new);
+    // heads: inline ids and the first three ids of every list
+#pragma unroll
+    for (int k = 0; k < NWIN; k++) {
+        const uint32_t pos = (uint32_t)(c0 + k * stride) + lane;
+        const uint32_t lcnt = h[k].x;
+        if (lcnt != 0u) {
+            c.post += lcnt;
+            if (!(v[k] & KH_INLINE_BIT)) { c.lists++; c.lids += lcnt; }
+        }
+        if (!COUNT_ONLY) {  // all lanes take part: run heads add for their whole run
+            ok = add_runs(tab, lcnt > 0 ? h[k].y : KH_EMPTY_PID, pos, nnew) && ok;
+            ok = add_runs(tab, lcnt > 1 ? h[k].z : KH_EMPTY_PID, pos, nnew) && ok;
+            ok = add_runs(tab, lcnt > 2 ? h[k].w : KH_EMPTY_PID, pos, nnew) && ok;
+        }
+    }
+    if (!COUNT_ONLY) {
+#pragma unroll
+        for (int k = 0; k < NWIN; k++)
+#pragma unroll
+            for (int it = 0; it < XIT; it++)
+                if (xid[k][it] != KH_EMPTY_PID) ok = ok && tab.add_n(xid[k][it], xpos[k][it], 1u, nnew);
+        const uint32_t wave_new = wave_total(nnew);
+        if (lane == 0 && wave_new) atomicAdd(tab.nd, wave_new);
+    }
     return __all(ok);
 }
 
 // sets bits [b, e) of the not-a-k-mer-start bitmap
 __device__ __forceinline__ void mark_invalid_range(unsigned long long *invalid, uint64_t b, uint64_t e)
 {
+    // sets bits [b, e)
     while (b < e) {
         const uint64_t w = b >> 6;
         const uint64_t hi = ((w + 1) << 6) < e ? ((w + 1) << 6) : e;
@@ -685,6 +601,8 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
 {
     constexpr int WAVES = G_WAVES;
     __shared__ uint32_t s_nd, s_fail, s_cursor;
+    constexpr int NWIN = 2;
+    __shared__ uint32_t s_pref[WAVES][NWIN * 64];
     __shared__ unsigned long long s_post, s_off, s_base;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
@@ -698,12 +616,13 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
         const WorkItem wi = p.list[item];
         const uint32_t q = wi.q;
         const int32_t size = wi.size;
+        const uint32_t *vals = p.vals + wi.aa_off;
         if (tid == 0) { s_nd = 0; s_fail = 0; s_post = 0; s_cursor = 0; }
         __syncthreads();
         // pass 1: exact number of postings (an upper bound of the distinct proteins)
         pc.clear();
-        for (int32_t r0 = 64 * (int32_t)wv; r0 < size; r0 += 64 * WAVES)
-            count_window<NullTable, true>(p, wi.aa_off, size, r0, nt, pc);
+        for (int32_t r0 = 0; r0 < size; r0 += 64 * WAVES * NWIN)
+            count_windows<NullTable, NWIN, true>(p, vals, size, r0 + 64 * (int32_t)wv, 64 * WAVES, nt, pc, s_pref[wv]);
         {
             const unsigned long long wp = wave_total(pc.post);
             if (lane == 0 && wp) atomicAdd(&s_post, wp);
@@ -739,8 +658,9 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
         __syncthreads();
         // pass 2: count
         pc.clear();
-        for (int32_t r0 = 64 * (int32_t)wv; r0 < size; r0 += 64 * WAVES) {
-            const bool ok = count_window<GlobalTable, false>(p, wi.aa_off, size, r0, gt, pc);
+        for (int32_t r0 = 0; r0 < size; r0 += 64 * WAVES * NWIN) {
+            const bool ok = count_windows<GlobalTable, NWIN, false>(p, vals, size, r0 + 64 * (int32_t)wv, 64 * WAVES, gt,
+                                                                   pc, s_pref[wv]);
             if (!ok) s_fail = 1;
         }
         __syncthreads();
@@ -823,7 +743,9 @@ struct BitsTable {
 __global__ __launch_bounds__(64 * G_WAVES) void positions_global_kernel(CountParams p)
 {
     constexpr int WAVES = G_WAVES;
+    constexpr int NWIN = 2;
     __shared__ uint32_t s_nd;
+    __shared__ uint32_t s_pref[WAVES][NWIN * 64];
     __shared__ unsigned long long s_off;
     const uint32_t tid = threadIdx.x, wv = tid >> 6;
     const uint32_t n_items = *p.list_count < p.list_cap ? *p.list_count : p.list_cap;
@@ -862,8 +784,8 @@ __global__ __launch_bounds__(64 * G_WAVES) void positions_global_kernel(CountPar
         bt.bits = p.pos_bits + p.pos_base[q];
         pc.clear();
         bool ok = true;
-        for (int32_t r0 = 64 * (int32_t)wv; r0 < size; r0 += 64 * WAVES)
-            ok = count_window<BitsTable, false>(p, wi.aa_off, size, r0, bt, pc) && ok;
+        for (int32_t r0 = 0; r0 < size; r0 += 64 * WAVES * NWIN)
+            ok = count_windows<BitsTable, NWIN, false>(p, p.vals + wi.aa_off, size, r0 + 64 * (int32_t)wv, 64 * WAVES, bt, pc, s_pref[wv]) && ok;
         if (!ok && (tid & 63u) == 0) atomicOr(p.status, (uint32_t)ST_G_TABLE_FULL);
         __syncthreads();
     }
@@ -1030,9 +952,8 @@ struct kaamer_workspace {
     kaamer_query_meta *d_q;
     uint32_t *d_nq;
     unsigned long long *d_n_pos;
-    unsigned long long *d_valid;        // one bit per residue position: not a k-mer start
-    uint4 *d_rec;                       // the probe's records: pos_cap heads, then pos_cap continuations
-    uint32_t rec_epoch;                 // tag of the current batch's records
+    unsigned long long *d_valid;        // one bit per residue position
+    uint32_t *d_vals;                   // probe result per residue position
     uint32_t *d_q_cnt;
     unsigned long long *d_pool_cursor;  // CURSOR_STRIDE apart: G-tier tail cursor, G arena cursor (count), G arena cursor (positions)
     WorkItem *d_lists;                  // [N_LISTS][q_cap] (only the G tier's overflow list is used)
@@ -1181,7 +1102,7 @@ void kaamer_workspace_free(kaamer_workspace *ws)
 {
     if (!ws) return;
     (void)hipSetDevice(ws->device);
-    void *bufs[] = { ws->d_q, ws->d_nq, ws->d_n_pos, ws->d_valid, ws->d_rec, ws->d_cnt3, ws->d_off3, ws->d_n6, ws->d_long_seq, ws->d_long_np, ws->d_pcnt3, ws->d_n_piece_items, ws->d_piece_base, ws->d_poff3,
+    void *bufs[] = { ws->d_q, ws->d_nq, ws->d_n_pos, ws->d_valid, ws->d_vals, ws->d_cnt3, ws->d_off3, ws->d_n6, ws->d_long_seq, ws->d_long_np, ws->d_pcnt3, ws->d_n_piece_items, ws->d_piece_base, ws->d_poff3,
                      ws->d_tmp_meta, ws->d_orf_aa, ws->d_starts_alt, ws->d_q_cnt, ws->d_csr_off, ws->d_c_pid, ws->d_c_km, ws->d_c_fp,
                      ws->d_pool_cursor, ws->d_lists, ws->d_list_counts, ws->d_status_out, ws->d_qinfo, ws->d_slots,
                      ws->d_slot_off, ws->d_group_first, ws->d_n_groups, ws->d_pos_words, ws->d_pos_base, ws->d_pos_off, ws->d_pos_bits, ws->d_g_keys,
@@ -1238,15 +1159,15 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&grp_per_cu, count_group_kernel<false, 0>, 64 * GRP_WAVES, 0);
     if (oe == hipSuccess) oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&p_per_cu, probe_kernel, 64 * P_WAVES, 0);
     if (oe != hipSuccess) { delete ws; return kaamer_fail(KAAMER_E_HIP, "occupancy query: %s", hipGetErrorString(oe)); }
-    if (p_per_cu < 1) p_per_cu = 1;
     hipDeviceProp_t prop;
     hipError_t pe = hipGetDeviceProperties(&prop, ix->device);
     if (pe != hipSuccess) { delete ws; return kaamer_fail(KAAMER_E_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(pe)); }
     if (grp_per_cu < 1) grp_per_cu = 1;
+    if (p_per_cu < 1) p_per_cu = 1;
     ws->n_cu = prop.multiProcessorCount;
     ws->grp_grid = ws->n_cu * grp_per_cu;
-    ws->p_grid = ws->n_cu * p_per_cu;
     ws->g_grid = ws->n_cu / 2;  // the G tier is rare; its last workgroup also finalizes the batch (one atomic per workgroup)
+    ws->p_grid = ws->n_cu * p_per_cu;
     // a table has at most max(64, 3 x SizeInKmer) slots
     {
         const uint64_t gc = ((uint64_t)GRP_MIN_TABLE * ws->q_cap + 3 * ws->pos_cap) / GRP_BUDGET + 4;
@@ -1268,9 +1189,7 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     if (!rc) rc = dev_alloc(&ws->d_nq, 1);
     if (!rc) rc = dev_alloc(&ws->d_n_pos, 1);
     if (!rc) rc = dev_alloc(&ws->d_valid, (size_t)(ws->pos_cap / 64 + 2));
-    if (!rc) rc = dev_alloc(&ws->d_rec, (size_t)ws->pos_cap * 2);
-    // a record counts only if its first word carries the current batch's tag (tags start at 1)
-    if (!rc && hipMemset(ws->d_rec, 0, (size_t)ws->pos_cap * sizeof(uint4)) != hipSuccess) rc = kaamer_fail(KAAMER_E_HIP, "memset");
+    if (!rc) rc = dev_alloc(&ws->d_vals, (size_t)ws->pos_cap);
     if (!rc && ws->nucleotide) {
         const size_t n6 = (size_t)ws->max_seqs * 6;
         rc = dev_alloc(&ws->d_cnt3, 3 * n6);
@@ -1388,7 +1307,6 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     if (!nucl && seq_type != KAAMER_PROTEIN) return kaamer_fail(KAAMER_E_ARG, "search_device: unknown sequence type %d", seq_type);
     if (nucl != ws->nucleotide) return kaamer_fail(KAAMER_E_ARG, "workspace was created for %s input", ws->nucleotide ? "nucleotide" : "protein");
     if (n_seqs > ws->max_seqs) return kaamer_fail(KAAMER_E_CAPACITY, "batch of %u sequences exceeds workspace max_seqs %u", n_seqs, ws->max_seqs);
-    if (ws->pos_cap > 0xFFFFFFF0ull) return kaamer_fail(KAAMER_E_CAPACITY, "a batch holds at most 2^32 residue positions");
     if (seq_bytes > ws->opts.max_seq_bytes) return kaamer_fail(KAAMER_E_CAPACITY, "batch of %llu bytes exceeds workspace max_seq_bytes", (unsigned long long)seq_bytes);
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(ix->device));
@@ -1508,27 +1426,16 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
 
     // ---- kernel P: flat probe
     ProbeParams pp;
-    memset(&pp, 0, sizeof pp);
-    pp.tab.cells = reinterpret_cast<const uint4 *>(ix->d_buckets);
-    pp.tab.arena = ix->d_arena;
-    pp.tab.n_buckets = ix->hdr.n_buckets;
-    pp.tab.n_shards = ix->hdr.n_shards;
-    pp.tab.shard = ix->hdr.shard;
-    // nontemporal when the batch is small against the table (a bucket is then read once per batch); a
-    // 1 M-read batch touches every bucket several times and wants them cached
-    pp.tab.nontemporal = pos_bound < ix->hdr.n_buckets ? 1u : 0u;
-    if (const char *e = getenv("KAAMER_NT")) pp.tab.nontemporal = (uint32_t)atoi(e);  // tuning experiments only
+    pp.table = reinterpret_cast<const uint4 *>(ix->d_buckets);
+    pp.n_buckets = ix->hdr.n_buckets;
+    pp.n_shards = ix->hdr.n_shards;
+    pp.shard = ix->hdr.shard;
     pp.residues = residues;
     pp.invalid = ws->d_valid;
     pp.d_n_pos = ws->d_n_pos;
-    pp.rec = ws->d_rec;
-    pp.rec2 = ws->d_rec + ws->pos_cap;
-    if (++ws->rec_epoch == 0u) {  // the tag wrapped (2^32 batches): old records must not be taken for new ones
-        HIPCHK(hipMemsetAsync(ws->d_rec, 0, (size_t)ws->pos_cap * sizeof(uint4), s));
-        ws->rec_epoch = 1u;
-    }
-    pp.epoch = ws->rec_epoch;
+    pp.vals = ws->d_vals;
     pp.counters = ws->d_counter_replicas;
+    pp.nontemporal = pos_bound < ix->hdr.n_buckets ? 1u : 0u;
     uint64_t p_blocks = (pos_bound / 64 + 1 + P_WAVES - 1) / P_WAVES;
     if (p_blocks > (uint64_t)ws->p_grid) p_blocks = ws->p_grid;
     if (p_blocks < 1) p_blocks = 1;
@@ -1539,9 +1446,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     CountParams p;
     memset(&p, 0, sizeof p);
     p.arena = ix->d_arena;
-    p.rec = ws->d_rec;
-    p.rec2 = ws->d_rec + ws->pos_cap;
-    p.epoch = ws->rec_epoch;
+    p.vals = ws->d_vals;
     p.qinfo = ws->d_qinfo;
     p.slot_off = ws->d_slot_off;
     p.group_first = ws->d_group_first;

@@ -12,7 +12,7 @@ python3 - <<PY
 import json,glob
 for f in ("protein","reads"):
     j=json.load(open("$O/%s.json"%f)); r=j["roofline"]
-    print(f, "value %.3e ms/batch %.4f frac %.3f | kernel ms %.4f frac %.3f Greq/s %.1f | other %.4f"%(j["value"], j["config"]["ms_per_batch"], r["frac"], r["dominant_kernel"]["ms"], r["dominant_kernel"]["frac"], r["dominant_kernel"]["G_random_requests_per_s"], r["other_kernels_ms"]))
+    print(f, "value %.3e ms/batch %.4f frac %.3f | %s ms %.4f frac %.3f | %s ms %.4f frac %.3f"%(j["value"], j["config"]["ms_per_batch"], r["frac"], r["dominant_kernel"]["name"][:12], r["dominant_kernel"]["ms"], r["dominant_kernel"]["frac"], r["other_kernels"][0]["name"][:12], r["other_kernels"][0]["ms"], r["other_kernels"][0]["frac"]))
     print(j["counters_per_batch_rank0"])
 for d in ("stats_protein","stats_reads"):
     fs=glob.glob("$O/%s/*/*_kernel_stats.csv"%d)
