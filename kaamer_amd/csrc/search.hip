@@ -165,115 +165,141 @@ struct ProbeParams {
 };
 
 #define P_WAVES 4
+#define P_RING 128u            /* deferred lookups per wave (a power of two): fewer than 64 waiting + the 64 of a window */
+#define KH_NO_KEY 0xFFFFFFFDu  /* "no lookup for this position": equals no slot key (valid keys <= 0xE773B9D4, 0xFFFFFFFF = empty) */
 
 __global__ __launch_bounds__(64 * P_WAVES) void probe_kernel(ProbeParams p)
 {
     __shared__ uint8_t s_lut[256];
     __shared__ uint8_t s_stage[P_WAVES][80];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    // Lookups whose bucket is full and does not hold the key (about 2 %) go on in the NEXT bucket of the probe sequence.
+    // Waiting for that second request inside the window stalls the whole wave (three windows out of four have such a
+    // lookup), so they are put on a ring in LDS (key, position, buckets walked) and looked up later, 64 at a time, as an
+    // iteration of their own through the same code.  The loop body is ONE straight line for both kinds of iteration, and
+    // every global load and store in it is issued unconditionally (idle lanes and idle iterations touch harmless
+    // addresses): the compiler's s_waitcnt vmcnt(N) then counts exactly -- a load or store inside a branch or an inner
+    // loop anywhere in the body makes every wait of the loop a vmcnt(0).
+    __shared__ uint32_t s_ring[P_WAVES][3][P_RING];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));  // wave-uniform: window bases stay scalar
     const unsigned long long n_pos = *p.d_n_pos;
     const unsigned long long n_win = (n_pos + 63) >> 6;
     for (uint32_t i = tid; i < 256; i += 64 * P_WAVES) s_lut[i] = (uint8_t)kh_residue_code((uint8_t)i);
     __syncthreads();  // the only workgroup barrier: the waves run independently from here on
     uint32_t c_lookup = 0, c_probe = 0, c_found = 0;
     uint8_t *stage = s_stage[wv];
+    uint32_t *const ring_key = s_ring[wv][0], *const ring_pos = s_ring[wv][1], *const ring_step = s_ring[wv][2];
+    uint32_t ring_head = 0, ring_n = 0;  // wave-uniform
+    const uint32_t n_buckets = (uint32_t)p.n_buckets;
+    const uint32_t mine = 16u * (lane & 3u) + (lane >> 2);  // the lane whose lookup this lane ends up owning (see the rounds)
 
     const unsigned long long stride = (unsigned long long)gridDim.x * P_WAVES;
     unsigned long long w = (unsigned long long)blockIdx.x * P_WAVES + wv;
-    // software pipeline: the bitmap word and the residues of the NEXT window are in flight
-    // while the buckets of the current one are fetched
+    // the bitmap word and the residues of the NEXT window are loaded behind the bucket loads of the current one;
+    // windows and reads past the end are clamped (the positions involved are marked invalid or unused)
     unsigned long long mask = 0;
     uint32_t ra = 0, rb = 0;
     auto fetch = [&](unsigned long long win, unsigned long long &m, uint32_t &a, uint32_t &b) {
-        m = 0; a = 0; b = 0;
-        if (win < n_win) {
-            m = ~p.invalid[win];
-            const unsigned long long i0 = (win << 6) + lane;
-            if (i0 < n_pos) a = p.residues[i0];
-            if (lane < 6 && i0 + 64 < n_pos) b = p.residues[i0 + 64];
-        }
+        const unsigned long long wc = win < n_win ? win : n_win - 1;
+        m = p.invalid[wc];
+        const unsigned long long i0 = (wc << 6) + lane, last = n_pos - 1;
+        a = p.residues[i0 < last ? i0 : last];
+        b = p.residues[i0 + 64 < last ? i0 + 64 : last];  // lanes 0..5 hold the halo
     };
-    fetch(w, mask, ra, rb);
+    if (n_win) fetch(w, mask, ra, rb);
 
-    for (; w < n_win; w += stride) {
-        const unsigned long long base = w << 6;
-        unsigned long long nmask;
-        uint32_t na, nb;
-        fetch(w + stride, nmask, na, nb);
-        if (lane == 0 && mask != ~0ull) p.invalid[w] = 0ull;  // leave the bitmap clean for the next batch
-
-        uint32_t key = KH_EMPTY_KEY;
-        if (mask) {
-            stage[lane] = (base + lane < n_pos) ? s_lut[ra] : (uint8_t)KH_CODE_UNKNOWN;
-            if (lane < 6) stage[64 + lane] = (base + 64 + lane < n_pos) ? s_lut[rb] : (uint8_t)KH_CODE_UNKNOWN;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if ((mask >> lane) & 1ull) {
-                const uint8_t *st = stage + lane;
-                key = kh_key_from_codes(st[0], st[1], st[2], st[3], st[4], st[5], st[6]);
-                // sharded index: this device probes only the keys it owns
-                if (p.n_shards > 1 && kh_shard_of(key, p.n_shards) != p.shard) key = KH_EMPTY_KEY;
+    while (n_win) {
+        const bool ring = ring_n >= 64u || (w >= n_win && ring_n > 0u);  // wave-uniform: this iteration serves the ring
+        if (!ring && w >= n_win) break;
+        unsigned long long base = 0;
+        uint32_t key = KH_NO_KEY, off = lane, step = 0;
+        if (ring) {
+            const uint32_t n = ring_n < 64u ? ring_n : 64u;
+            if (lane < n) {
+                const uint32_t slot = (ring_head + lane) & (P_RING - 1u);
+                key = ring_key[slot]; off = ring_pos[slot]; step = ring_step[slot];
             }
+            ring_head = (ring_head + n) & (P_RING - 1u);
+            ring_n -= n;
+        } else {
+            base = w << 6;
+            stage[lane] = s_lut[ra];
+            if (lane < 6) stage[64 + lane] = s_lut[rb];
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            const uint8_t *st = stage + lane;
+            key = kh_key_from_codes(st[0], st[1], st[2], st[3], st[4], st[5], st[6]);
+            // not a k-mer start, or (sharded index) a key another device owns: no lookup, the position reads as absent
+            const bool own = p.n_shards <= 1 || kh_shard_of(key, p.n_shards) == p.shard;
+            key = (((~mask >> lane) & 1ull) && own) ? key : KH_NO_KEY;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            c_lookup += key != KH_NO_KEY ? 1u : 0u;
         }
-        const uint32_t bucket = (key != KH_EMPTY_KEY) ? (uint32_t)kh_home_bucket(key, p.n_shards, p.n_buckets) : 0u;
+        c_probe += key != KH_NO_KEY ? 1u : 0u;
+        // ---- the next regular window's inputs first (a ring iteration fetches the pending window's again): they are
+        // older than the bucket loads, so waiting for the buckets covers them, and the stores at the end of the
+        // iteration are younger than every load -- nothing ever waits for a store to be acknowledged
+        const unsigned long long w_cur = w;
+        if (!ring) w += stride;
+        fetch(w, mask, ra, rb);
 
-        // round j serves the k-mers of lanes 16j..16j+15; lane 4g+j ends up owning k-mer 16j+g
+        // ---- issue: round j serves the lookups of lanes 16j..16j+15, four lanes per 64-byte bucket (16 B each: one
+        // fabric sector per probe); nontemporal when the batch is small against the table (a bucket is then read once per
+        // batch; a 1 M-read batch touches every bucket several times and wants them cached)
         uint4 ld[4];
-        uint32_t rkey[4], rbk[4];
+        uint32_t rk[4], rs[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int src = 16 * j + (int)(lane >> 2);
-            rbk[j] = __shfl(bucket, src, 64);
-            rkey[j] = __shfl(key, src, 64);
-            ld[j] = make_uint4(KH_EMPTY_KEY, 0, KH_EMPTY_KEY, 0);
-            // nontemporal when the batch is small against the table (a bucket is then read once per
-            // batch): keeping it out of the way of the lines the counting kernel re-reads (vals, list
-            // heads) is worth 8 us per 10 000-query batch downstream.  A 1 M-read batch touches every
-            // bucket several times and wants them cached (+9 % probe time when nontemporal).
-            if (rkey[j] != KH_EMPTY_KEY) {
-                typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-                const v4u *src = reinterpret_cast<const v4u *>(p.table) + (uint64_t)rbk[j] * 4 + (lane & 3u);
-                const v4u t = p.nontemporal ? __builtin_nontemporal_load(src) : *src;
-                ld[j] = make_uint4(t.x, t.y, t.z, t.w);
+            rk[j] = __shfl(key, src, 64);
+            rs[j] = __shfl(step, src, 64);
+            uint32_t bucket = 0u;
+            if (rk[j] != KH_NO_KEY) {
+                bucket = (uint32_t)kh_home_bucket(rk[j], p.n_shards, p.n_buckets) + rs[j];
+                bucket = bucket >= n_buckets ? bucket - n_buckets : bucket;
             }
+            typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+            const v4u *srcp = reinterpret_cast<const v4u *>(p.table) + (uint64_t)bucket * 4 + (lane & 3u);
+            const v4u t = p.nontemporal ? __builtin_nontemporal_load(srcp) : *srcp;
+            ld[j] = make_uint4(t.x, t.y, t.z, t.w);
         }
-        uint32_t okey = KH_EMPTY_KEY, oval = 0, obucket = 0;
-        bool oempty = true;
+        // ---- consume: lane 4g+j ends up owning the lookup of lane 16j+g
+        uint32_t okey = KH_NO_KEY, oval = 0, oempty = 1u, ostep = 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const uint32_t kk = rkey[j];
+            const uint32_t kk = rk[j];
             uint32_t r = (ld[j].x == kk) ? ld[j].y : ((ld[j].z == kk) ? ld[j].w : 0u);
             uint32_t e = (ld[j].x == KH_EMPTY_KEY || ld[j].z == KH_EMPTY_KEY) ? 1u : 0u;
-            r |= __shfl_xor(r, 1, 64); e |= __shfl_xor(e, 1, 64);
-            r |= __shfl_xor(r, 2, 64); e |= __shfl_xor(e, 2, 64);
-            if ((lane & 3u) == (uint32_t)j) { okey = kk; oval = r; oempty = (e != 0u); obucket = rbk[j]; }
+            r |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
+            e |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)e, 0xB1, 0xf, 0xf, false);
+            r |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
+            e |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)e, 0x4E, 0xf, 0xf, false);
+            const bool take = (lane & 3u) == (uint32_t)j;
+            okey = take ? kk : okey; oval = take ? r : oval; oempty = take ? e : oempty; ostep = take ? rs[j] : ostep;
         }
-        const bool valid = okey != KH_EMPTY_KEY;
-        if (valid) { c_lookup++; c_probe++; }
-        // rare: home bucket full and key not in it -> this lane walks the following buckets alone
-        if (valid && oval == 0u && !oempty) {
-            for (uint64_t tries = 1; tries < p.n_buckets; tries++) {
-                obucket = (obucket + 1u == (uint32_t)p.n_buckets) ? 0u : obucket + 1u;
-                c_probe++;
-                bool e = false;
-#pragma unroll
-                for (int s = 0; s < 4; s++) {
-                    const uint4 v = p.table[(uint64_t)obucket * 4 + s];
-                    if (v.x == okey) oval = v.y;
-                    if (v.z == okey) oval = v.w;
-                    e = e || v.x == KH_EMPTY_KEY || v.z == KH_EMPTY_KEY;
-                }
-                if (oval != 0u || e) break;
+        const uint32_t ooff = __shfl(off, (int)mine, 64);  // position of the lookup this lane owns (window offset, or absolute)
+        const bool valid = okey != KH_NO_KEY;
+        c_found += (valid && oval != 0u) ? 1u : 0u;
+        // the key is not in this bucket and the bucket is full: the lookup goes on one bucket further, from the ring
+        const bool wk = valid && oval == 0u && oempty == 0u && ostep + 1u < n_buckets;
+        const unsigned long long W = __ballot(wk);
+        if (W) {  // wave-uniform; LDS only
+            if (wk) {
+                const uint32_t slot = (ring_head + ring_n + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(W >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)W, 0u))) & (P_RING - 1u);
+                ring_key[slot] = okey;
+                ring_pos[slot] = (uint32_t)base + ooff;  // positions fit 32 bits (checked on the host)
+                ring_step[slot] = ostep + 1u;
             }
+            ring_n += (uint32_t)__popcll(W);
         }
-        if (valid && oval != 0u) c_found++;
-        // the owner lane writes the position it owns: 16*(lane&3) + (lane>>2)
-        const unsigned long long opos = base + 16u * (lane & 3u) + (lane >> 2);
-        if (opos < n_pos) p.vals[opos] = valid ? oval : 0u;
-
-        mask = nmask; ra = na; rb = nb;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // one coalesced store per window: vals[i] = 0 (key absent, or not a k-mer start) or slot.val; a ring iteration
+        // stores only what it found (the regular pass has already written 0 there)
+        if (!ring || oval != 0u) p.vals[base + ooff] = oval;
+        // leave the bitmap clean for the next batch (a ring iteration stores into the slack word behind the bitmap)
+        if (lane == 0) p.invalid[ring ? n_win + 1 : w_cur] = 0ull;
     }
     const uint32_t t_lookup = wave_total(c_lookup), t_probe = wave_total(c_probe), t_found = wave_total(c_found);
     if (lane == 0) {
@@ -1307,6 +1333,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     if (!nucl && seq_type != KAAMER_PROTEIN) return kaamer_fail(KAAMER_E_ARG, "search_device: unknown sequence type %d", seq_type);
     if (nucl != ws->nucleotide) return kaamer_fail(KAAMER_E_ARG, "workspace was created for %s input", ws->nucleotide ? "nucleotide" : "protein");
     if (n_seqs > ws->max_seqs) return kaamer_fail(KAAMER_E_CAPACITY, "batch of %u sequences exceeds workspace max_seqs %u", n_seqs, ws->max_seqs);
+    if (ws->pos_cap > 0xFFFFFFF0ull) return kaamer_fail(KAAMER_E_CAPACITY, "a batch holds at most 2^32 residue positions");
     if (seq_bytes > ws->opts.max_seq_bytes) return kaamer_fail(KAAMER_E_CAPACITY, "batch of %llu bytes exceeds workspace max_seq_bytes", (unsigned long long)seq_bytes);
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(ix->device));
