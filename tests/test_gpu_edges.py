@@ -1,0 +1,131 @@
+"""Edge cases of the hot path against the CPU oracle, through the C ABI:
+  * a query of more than 65 535 k-mers with first positions (16-bit packed counts/positions of the LDS
+    tables do not hold it: the G tier must take it);
+  * postings lists of more than 10 000 proteins (the very-long-list expansion, tables that overflow);
+  * '.' in the database and in the queries (aaTable[{a,'.'}], k_store.go:48-52,102-103);
+  * every byte value below 0x80 in nucleotide input (strings.ToLower + map misses, dna.go:68,106)."""
+import numpy as np
+import pytest
+
+from kaamer_amd import abi
+
+pytestmark = pytest.mark.gpu
+
+
+def _expect(oracle, oix, s, positions=True):
+    size = oracle.size_in_kmer(s)
+    if size < 7:
+        return {}, {}
+    pid, km, pos = oix.search(s, want_positions=positions)
+    fp = {int(p): int(np.argmax(pos[j])) for j, p in enumerate(pid)} if positions else {}
+    return dict(zip(pid.tolist(), km.tolist())), fp
+
+
+def test_query_longer_than_65535_kmers(klib, oracle, gpu_device):
+    from kaamer_amd import api, workload
+    db = workload.make_db(3000, seed=21)
+    ix = api.Index.from_image(api.Image.from_proteins(packed=db), gpu_device)
+    oix = oracle.Index.from_proteins(None, packed=db)
+    recs = workload.unpack(db)
+    rng = np.random.default_rng(5)
+    long_q = b"".join(recs[int(i)] for i in rng.integers(0, len(recs), 260))   # ~90 000 residues, hits everywhere
+    assert len(long_q) - 6 > 70000
+    qs = [recs[3], long_q, recs[17][:40], long_q[1000:70000]]
+    res = ix.search(qs)                   # first positions on (PACKED tables): the long queries leave the LDS tier
+    assert res.counters["n_overflow"] >= 2
+    for i, s in enumerate(qs):
+        exp, fp = _expect(oracle, oix, s)
+        assert res.hits(i) == exp, "query %d" % i
+        assert res.first_pos(i) == fp, "query %d" % i
+    assert max(res.hits(1).values()) < 65535 and len(res.hits(1)) > 200
+    # and full PositionHits bitmaps for the same batch
+    resp = ix.search(qs, want_positions=True)
+    for i, s in enumerate(qs):
+        size = oracle.size_in_kmer(s)
+        pid, km, pos = oix.search(s, want_positions=True)
+        got = resp.positions(i)
+        assert set(got) == set(pid.tolist())
+        for j in range(0, len(pid), max(1, len(pid) // 40)):
+            assert (got[int(pid[j])] == pos[j]).all(), (i, int(pid[j]))
+
+
+def test_postings_lists_of_ten_thousand(klib, oracle, gpu_device):
+    """12 000 proteins share one 20-residue motif: its 14 k-mers have postings lists of 12 000 ids."""
+    from kaamer_amd import api, workload
+    rng = np.random.default_rng(9)
+    aa = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
+    motif = bytes(aa[rng.integers(0, 20, 20)])
+    motif2 = bytes(aa[rng.integers(0, 20, 12)])
+    seqs = []
+    for i in range(12000):
+        body = bytearray(bytes(aa[rng.integers(0, 20, 60)]))
+        body[20:40] = motif
+        if i % 3 == 0:
+            body[44:56] = motif2              # a second family of 4 000
+        seqs.append(bytes(body))
+    img = api.Image.from_proteins(seqs)
+    assert img.stats()["max_list"] == 12000
+    ix = api.Index.from_image(img, gpu_device)
+    oix = oracle.Index.from_proteins(seqs)
+    fill = lambda n: bytes(aa[rng.integers(0, 20, n)])
+    qs = [fill(30) + motif + fill(30),                    # 14 positions x 12 000 ids: > 4096 distinct hits -> G tier
+          seqs[7], seqs[9], motif + motif2 + motif,       # several long lists in one window
+          fill(200), motif[:13] + fill(5) + motif2,
+          (fill(10) + motif) * 20]                        # 280 positions x 12 000 ids = 3.4 M postings for one query
+    res = ix.search(qs)
+    assert res.counters["n_overflow"] >= 3 and res.counters["n_post"] > 3_000_000
+    for i, s in enumerate(qs):
+        exp, fp = _expect(oracle, oix, s)
+        assert res.hits(i) == exp, "query %d" % i
+        assert res.first_pos(i) == fp, "query %d" % i
+    top = ix.search_top(qs)                               # 12 000 hits with massive ties through the device top-N
+    tp, tk = top.dense()
+    for i, s in enumerate(qs):
+        size = oracle.size_in_kmer(s)
+        pid, km, _ = oix.search(s)
+        keep = oracle.filter_results(km, size) if len(km) else 0
+        assert int(top.top_cnt[i]) == keep
+        assert tp[i, :keep].tolist() == pid[:keep].tolist() and tk[i, :keep].tolist() == km[:keep].tolist()
+
+
+def test_dot_in_database_and_queries(klib, oracle, gpu_device):
+    from kaamer_amd import api
+    rng = np.random.default_rng(13)
+    alpha = np.frombuffer(b"ACDEFGHIKLMNPQRSTUVWY...XB*", dtype=np.uint8)   # '.' over-represented, a few non-letters
+    seqs = [bytes(alpha[rng.integers(0, len(alpha), int(n))]) for n in rng.integers(20, 200, 400)]
+    seqs += [b"C.AAAAA" * 4, b"Y.Y.Y.Y.Y.Y.Y", b"......." * 3, b"AAAAAA.AAAAAA."]
+    ix = api.Index.from_image(api.Image.from_proteins(seqs), gpu_device)
+    oix = oracle.Index.from_proteins(seqs)
+    assert abi.lib().kaamer_encode_kmer(b"C.AAAAA") == 0x008582C0 == oracle.encode_kmer("C.AAAAA")
+    qs = [seqs[i] for i in range(0, len(seqs), 7)] + [b"C.AAAAA", b"Y.Y.Y.Y", b"CAAAAAAAA", b"A.A.A.A.A.A.A.A"]
+    qs += [bytes(alpha[rng.integers(0, len(alpha), 80)]) for _ in range(40)]
+    res = ix.search(qs)
+    n = 0
+    for i, s in enumerate(qs):
+        exp, fp = _expect(oracle, oix, s)
+        assert res.hits(i) == exp, "query %d %r" % (i, s)
+        assert res.first_pos(i) == fp
+        n += len(exp)
+    assert n > 200
+
+
+def test_reads_with_every_byte_value(klib, oracle, gpu_device):
+    """Nucleotide input with every byte below 0x80 in it (upper / lower case, N, digits, punctuation): ORFs as the
+    reference finds them (ToLower, then any codon with a byte other than a/c/g/t is a map miss)."""
+    from kaamer_amd import api, workload
+    from test_gpu_reads import _check_reads
+    db = workload.make_db(500, seed=3)
+    ix = api.Index.from_image(api.Image.from_proteins(packed=db), gpu_device)
+    oix = oracle.Index.from_proteins(None, packed=db)
+    base = workload.unpack(workload.make_reads(db, 256, seed=31))
+    rng = np.random.default_rng(2)
+    reads = []
+    for i, r in enumerate(base):
+        b = bytearray(r.lower() if i % 2 else r)
+        for _ in range(3):                                    # three foreign bytes per read, all 128 values covered
+            b[int(rng.integers(0, len(b)))] = (i // 2 + int(rng.integers(0, 128))) % 128
+        b[int(rng.integers(0, len(b)))] = i % 128
+        reads.append(bytes(b))
+    assert len({c for r in reads for c in r}) == 128
+    res = ix.search(reads, seq_type=abi.READS)
+    assert _check_reads(res, reads, oracle, oix, check_hits=True) > 300
