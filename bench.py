@@ -132,12 +132,23 @@ def main():
                          "FilterResults: kaamer_topn_device with the reference's defaults)")
     ap.add_argument("--host-api", type=int, default=0,
                     help="1: also time the host-buffer calls once (PCIe-inclusive, informational, never `value`)")
+    ap.add_argument("--exchange-entries", type=int, default=0,
+                    help="sharded mode: partial hit entries one exchange block holds (default: sized for the workload)")
     ap.add_argument("--inflight", type=int, default=1,
                     help="batches in flight: batch i runs on workspace/stream i %% inflight")
     ap.add_argument("--compact", type=int, default=0,
                     help="1: finish every batch with the hit lists packed in query order (one more scan + copy pass); "
                          "0 (default): each query's list stays where the search kernel wrote it (offset + count per query)")
     args = ap.parse_args()
+
+    # stdout carries ONE line, the JSON: everything else a library prints there (RCCL's version banner at
+    # communicator creation, for one) goes to stderr
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    sys.stdout = os.fdopen(os.dup(2), "w")
+
+    def emit(line):
+        os.write(json_fd, (line + "\n").encode())
 
     nucl = args.workload in ("reads", "mix")
     if args.queries <= 0:
@@ -198,15 +209,18 @@ def main():
 
     if sharded_mode:
         from kaamer_amd import sharded
-        assert not nucl, "sharded mode: protein workload only until the exchange moves under the C ABI"
-        sws = api.Workspace(ix, max_bytes, args.queries, first_pos=1, **ws_kw)
-        mws = api.Workspace(ix, max_bytes, args.queries, first_pos=1, max_hits=16 << 20)
-        searcher = sharded.ShardedSearcher(ix, sws, mws, rank, world)
+        tstream = torch.cuda.current_stream()
+        ent = args.exchange_entries or ((96 << 20) if nucl else (4 << 20)) // world + (1 << 16)
+        searcher = sharded.ShardedSearcher(ix, rank, world, max_bytes, args.queries, seq_type=seq_type,
+                                           max_entries_per_peer=ent, max_hits=(64 << 20) if nucl else 0)
 
         def launch(i):
             b = i % n_distinct
-            return searcher.step(d_bufs[b], d_offs[b], args.queries, len(batches[b][0]), stream)[0]
-        wss, streams = [mws], [stream]
+            r = searcher.step(d_bufs[b].data_ptr(), d_offs[b].data_ptr(), args.queries, len(batches[b][0]), tstream)
+            if args.post:
+                searcher.topn(tstream)
+            return r
+        wss, streams = [searcher.ws], [stream]
     else:
         wss = [api.Workspace(ix, max_bytes, args.queries, **ws_kw) for _ in range(args.inflight)]
         extra_streams = [torch.cuda.Stream() for _ in range(args.inflight - 1)]  # kept alive
@@ -221,6 +235,8 @@ def main():
 
     def finish_all():
         c = None
+        if sharded_mode:
+            return searcher.finish(tstream)[0]
         for w_, s_ in zip(wss, streams):
             c = w_.finish(s_)   # also validates the batch (capacity / overflow)
         return c
@@ -229,8 +245,8 @@ def main():
     per_batch = []
     for b in range(n_distinct):
         if sharded_mode:
-            per_batch.append(searcher.step(d_bufs[b], d_offs[b], args.queries, len(batches[b][0]), stream)[2])
-            mws.finish(stream)
+            launch(b)
+            per_batch.append(searcher.finish(tstream)[0])
         else:
             wss[0].search_device(d_bufs[b].data_ptr(), d_offs[b].data_ptr(), args.queries, len(batches[b][0]), stream=streams[0])
             per_batch.append(wss[0].finish(streams[0]))
@@ -362,8 +378,6 @@ def main():
 
     if rank == 0:
         want_cpu = not args.no_cpu_baseline and world == 1 and not sharded_mode
-        if sharded_mode:
-            args.check = 0
         if args.check or want_cpu or args.host_api:
             from oracle import oracle as O  # the checker / the reported CPU baseline, never the product
             t0 = time.time()
@@ -375,7 +389,8 @@ def main():
                 from kaamer_amd.sharded import dev_tensor
                 sub = workload.unpack((q[0], q[1][:args.check + 1]))
                 counters = per_batch[last_batch]
-                nq_dev = int(counters["n_queries"])
+                stride = world if sharded_mode else 1   # sharded: result i of rank 0 is query i * world of the batch
+                nq_dev = (int(counters["n_queries"]) + stride - 1) // stride
                 cap = int(last.hit_capacity)
                 r_off = dev_tensor(last.d_hit_off, nq_dev, torch.int64).cpu().numpy()
                 r_cnt = dev_tensor(last.d_hit_cnt, nq_dev, torch.int32).cpu().numpy()
@@ -389,17 +404,20 @@ def main():
                     qi = 0
                     for s in sub:
                         for o in O.get_orfs(s):
-                            pid, km, _ = oix.search(o["seq"])
-                            assert hits(qi) == dict(zip(pid.tolist(), km.tolist())), "bench: ORF %d differs from the oracle" % qi
+                            if qi % stride == 0:
+                                pid, km, _ = oix.search(o["seq"])
+                                assert hits(qi // stride) == dict(zip(pid.tolist(), km.tolist())), "bench: ORF %d differs from the oracle" % qi
                             qi += 1
-                    assert qi <= nq_dev
+                    assert (qi + stride - 1) // stride <= nq_dev
                 else:
                     for i, s in enumerate(sub):
+                        if i % stride:
+                            continue
                         exp = {}
                         if O.size_in_kmer(s) >= 7:
                             pid, km, _ = oix.search(s)
                             exp = dict(zip(pid.tolist(), km.tolist()))
-                        assert hits(i) == exp, "bench: query %d differs from the oracle" % i
+                        assert hits(i // stride) == exp, "bench: query %d differs from the oracle" % i
                 out["parity_checked_queries"] = len(sub)
                 log("parity: %d queries of the last timed batch bit-exact vs oracle" % len(sub))
             if args.host_api:
@@ -414,7 +432,7 @@ def main():
                 out["host_buffer_calls_pcie_inclusive"] = hb
             if want_cpu:
                 out["cpu_baseline"] = cpu_baseline(oix, q, seconds=args.cpu_seconds, kind="reads" if nucl else "protein")
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     if world > 1 or sharded_mode:
         dist.barrier()
         dist.destroy_process_group()

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define KAAMER_ABI_VERSION 1
+#define KAAMER_ABI_VERSION 2
 #define KAAMER_KMER_SIZE 7 /* pkg/search/search.go:45, pkg/makedb/makedb.go:30 */
 
 typedef enum {
@@ -252,7 +252,14 @@ typedef struct {
     uint32_t max_results;      /* SearchOptions.MaxResults (default 10)        */
     uint32_t best_start_codon; /* 1: SetBestStartCodon first (nucleotide/reads)*/
     const int32_t *d_size_in_kmer; /* device, per query; NULL = the search's   */
-                               /* own queries; required after kaamer_merge_device */
+                               /* own queries; after a merge: this, or orf_source */
+    /* merged results of a sharded index: result i belongs to query             */
+    /* q_first + i * q_stride of ANOTHER workspace's last search (the owner's    */
+    /* own translation of the batch: rank r owns queries r, r+W, ...), whose     */
+    /* ORFs, StartsAlternative and SizeInKmer the post-steps then use            */
+    /* (SetBestStartCodon included).  NULL: the workspace's own queries.         */
+    const struct kaamer_workspace *orf_source;
+    uint32_t q_first, q_stride;
 } kaamer_topn_opts;
 
 typedef struct {
@@ -295,6 +302,53 @@ typedef struct {
 int kaamer_search_batch_top(kaamer_index *ix, const kaamer_batch_in *in, const kaamer_topn_opts *top,
                             kaamer_batch_top **out);
 void kaamer_batch_top_free(kaamer_batch_top *out);
+
+/* ------------------------------------------------------------------------- */
+/* Sharded index, the exchange step as device code (no reference counterpart:  */
+/* kaamer is one process; the result must equal the per-query block            */
+/* search_fastq.go:94-118 / search_protein.go:78-105 run against the whole DB). */
+/* One process per GPU; rank r holds shard r (kaamer_image_build_* (r, W)),     */
+/* every rank searches the WHOLE batch (nucleotide input: every rank            */
+/* translates, so all ranks number the ORFs alike), query q is owned by rank    */
+/* q mod W.  Per batch, on the caller's stream and without host synchronisation: */
+/*   kaamer_search_device(shard)           partial hit lists of all queries      */
+/*   kaamer_exchange_pack                  -> W fixed-size blocks, one per owner  */
+/*   all-to-all with equal splits          grouped ncclSend/ncclRecv (RCCL over   */
+/*                                         xGMI), the caller's communicator, or   */
+/*                                         kaamer_rccl_alltoall below             */
+/*   kaamer_exchange_merge(owner ws)       received blocks -> merged hit lists of  */
+/*                                         the owned queries (integer sums: bit-   */
+/*                                         identical to the one-device result)     */
+/*   kaamer_topn_device(owner ws, orf_source = the search workspace, q_first =     */
+/*                      rank, q_stride = W)                                        */
+/* Block capacities are bounds like every workspace bound: exceeding them is      */
+/* reported as KAAMER_E_CAPACITY by kaamer_workspace_finish, never a partial       */
+/* result.                                                                         */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    uint32_t world, rank;
+    uint32_t q_cap;        /* owned queries a block can describe                 */
+    uint32_t reserved;
+    uint64_t e_cap;        /* partial (id, Kmatch, first position) entries/block */
+    uint64_t block_words;  /* u32 words per block; send / receive buffers hold   */
+                           /* world blocks                                       */
+} kaamer_exchange_layout;
+
+/* max_queries: the search workspace's query capacity (kaamer_workspace_query_capacity) */
+int kaamer_exchange_layout_init(uint32_t world, uint32_t rank, uint32_t max_queries,
+                                uint64_t max_entries_per_peer, kaamer_exchange_layout *out);
+uint32_t kaamer_workspace_query_capacity(const kaamer_workspace *ws);
+/* the last search of `search_ws` -> d_send[world * block_words] */
+int kaamer_exchange_pack(kaamer_workspace *search_ws, const kaamer_exchange_layout *layout,
+                         uint32_t *d_send, void *stream);
+/* d_recv[world * block_words] (block s = what rank s sent to this rank) -> merged results in
+ * `merge_ws` (max_queries >= layout->q_cap, max_hits >= world * layout->e_cap, first_pos = 1) */
+int kaamer_exchange_merge(kaamer_workspace *merge_ws, const kaamer_exchange_layout *layout,
+                          const uint32_t *d_recv, void *stream, kaamer_device_result *out);
+/* Grouped ncclSend / ncclRecv of world equal blocks on `stream` with the caller's ncclComm_t.
+ * The library does not link RCCL: the symbols are taken from the process (or librccl.so.1). */
+int kaamer_rccl_alltoall(void *nccl_comm, const void *d_send, void *d_recv, uint64_t bytes_per_peer,
+                         uint32_t world, void *stream);
 
 /* Waits for `stream`, copies the counters to the host and reports a deferred
  * KAAMER_E_CAPACITY if a device-side bound was exceeded during the batch. */

@@ -79,7 +79,13 @@ class DeviceResult(C.Structure):
 
 class TopnOpts(C.Structure):
     _fields_ = [("min_k_ratio", C.c_double), ("min_k_match", C.c_int64), ("max_results", C.c_uint32),
-                ("best_start_codon", C.c_uint32), ("d_size_in_kmer", C.c_void_p)]
+                ("best_start_codon", C.c_uint32), ("d_size_in_kmer", C.c_void_p),
+                ("orf_source", C.c_void_p), ("q_first", C.c_uint32), ("q_stride", C.c_uint32)]
+
+
+class ExchangeLayout(C.Structure):
+    _fields_ = [("world", C.c_uint32), ("rank", C.c_uint32), ("q_cap", C.c_uint32), ("reserved", C.c_uint32),
+                ("e_cap", C.c_uint64), ("block_words", C.c_uint64)]
 
 
 class BatchTop(C.Structure):
@@ -123,6 +129,11 @@ SYMBOLS = {
                                        C.c_uint64, C.c_int32, C.c_void_p, C.POINTER(DeviceResult)]),
     "kaamer_merge_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64,
                                       C.c_void_p, C.POINTER(DeviceResult)]),
+    "kaamer_exchange_layout_init": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(ExchangeLayout)]),
+    "kaamer_workspace_query_capacity": (C.c_uint32, [C.c_void_p]),
+    "kaamer_exchange_pack": (C.c_int, [C.c_void_p, C.POINTER(ExchangeLayout), C.c_void_p, C.c_void_p]),
+    "kaamer_exchange_merge": (C.c_int, [C.c_void_p, C.POINTER(ExchangeLayout), C.c_void_p, C.c_void_p, C.POINTER(DeviceResult)]),
+    "kaamer_rccl_alltoall": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
     "kaamer_workspace_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(Counters)]),
     "kaamer_workspace_kernel_ms_sum": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                                  C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),

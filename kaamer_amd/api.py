@@ -238,7 +238,7 @@ class Index:
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
         offs = np.ascontiguousarray(offs, dtype=np.uint64)
         bi = abi.BatchIn(buf.ctypes.data if len(buf) else None, offs.ctypes.data, len(offs) - 1, seq_type, 0)
-        to = abi.TopnOpts(min_k_ratio, min_k_match, max_results, 0, None)
+        to = abi.TopnOpts(min_k_ratio, min_k_match, max_results, 0, None, None, 0, 0)
         out = C.POINTER(abi.BatchTop)()
         abi.check(abi.lib().kaamer_search_batch_top(self._h, C.byref(bi), C.byref(to), C.byref(out)))
         try:
@@ -289,11 +289,25 @@ class Workspace:
         return r
 
     def topn_device(self, min_k_ratio=0.05, min_k_match=10, max_results=10, best_start_codon=False,
-                    d_size_in_kmer_ptr=None, stream=0):
-        """sortMapByValue + (SetBestStartCodon) + FilterResults of the last search/merge, on the device"""
-        o = abi.TopnOpts(min_k_ratio, min_k_match, max_results, int(best_start_codon), d_size_in_kmer_ptr)
+                    d_size_in_kmer_ptr=None, stream=0, orf_source=None, q_first=0, q_stride=1):
+        """sortMapByValue + (SetBestStartCodon) + FilterResults of the last search/merge, on the device;
+        orf_source: the workspace whose queries the (merged) results belong to (result i = its query q_first + i q_stride)"""
+        o = abi.TopnOpts(min_k_ratio, min_k_match, max_results, int(best_start_codon), d_size_in_kmer_ptr,
+                         orf_source._h if orf_source is not None else None, q_first, q_stride)
         r = abi.TopnResult()
         abi.check(abi.lib().kaamer_topn_device(self._h, C.byref(o), C.c_void_p(stream), C.byref(r)))
+        return r
+
+    @property
+    def query_capacity(self):
+        return int(abi.lib().kaamer_workspace_query_capacity(self._h))
+
+    def exchange_pack(self, layout, d_send_ptr, stream=0):
+        abi.check(abi.lib().kaamer_exchange_pack(self._h, C.byref(layout), d_send_ptr, C.c_void_p(stream)))
+
+    def exchange_merge(self, layout, d_recv_ptr, stream=0):
+        r = abi.DeviceResult()
+        abi.check(abi.lib().kaamer_exchange_merge(self._h, C.byref(layout), d_recv_ptr, C.c_void_p(stream), C.byref(r)))
         return r
 
     def finish(self, stream=0):

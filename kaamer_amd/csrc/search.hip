@@ -32,6 +32,8 @@
 // tools/random_read_bench.hip), i.e. ~3.3 TB/s for 64-byte buckets.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
@@ -88,7 +90,7 @@ struct kaamer_index {
 };
 
 enum { ST_POOL_FULL = 1u, ST_LIST_FULL = 2u, ST_QUERY_CAP = 4u, ST_AA_CAP = 8u, ST_G_ARENA_FULL = 16u, ST_G_TABLE_FULL = 32u,
-       ST_POS_UNSUPPORTED = 64u, ST_POS_CAP = 128u, ST_CHAIN_TIMEOUT = 256u };
+       ST_POS_UNSUPPORTED = 64u, ST_POS_CAP = 128u, ST_CHAIN_TIMEOUT = 256u, ST_EXCHANGE_CAP = 512u };
 enum { CTR_IN = 0, CTR_QUERIES, CTR_LOOKUP, CTR_PROBE, CTR_FOUND, CTR_POST, CTR_HITS, CTR_OVERFLOW, CTR_LISTS, CTR_LIST_IDS, CTR_N };
 static_assert(sizeof(kaamer_counters) == CTR_N * 8, "counter layout");
 #define CTR_REPLICAS 64
@@ -932,6 +934,8 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_apply_kernel(const uint32_t *
     }
 }
 
+#include "exchange.hip.inc"
+
 // optional compaction: sharded hit arrays -> CSR in query order (one wave per query)
 __global__ __launch_bounds__(256) void gather_hits_kernel(const uint32_t *d_nq, const uint64_t *csr_off, const uint64_t *hit_off,
                                                           const uint32_t *q_cnt, const uint32_t *in_pid, const uint32_t *in_km,
@@ -1015,6 +1019,11 @@ struct kaamer_workspace {
     uint32_t *d_top_cnt, *d_top_pid, *d_top_km, *d_top_fp;
     int32_t *d_top_trim, *d_top_start, *d_top_size;
     bool last_was_merge;
+    // exchange step of the sharded index (kaamer_exchange_pack / _merge), allocated on first use
+    uint32_t x_world, x_qcap;
+    uint64_t x_ecap;
+    uint32_t *d_x_dst_off, *d_x_src_off, *d_x_nq_owned, *d_x_pid, *d_x_km, *d_x_fp;
+    uint64_t *d_x_ent_off;
     // reported-only packing of the top-N results (kaamer_search_batch_top), allocated on first use
     uint32_t rep_k;
     uint32_t *d_rep_flag, *d_rep_aalen, *d_rep_query, *d_rep_pid, *d_rep_km, *d_rep_fp;
@@ -1133,7 +1142,7 @@ void kaamer_workspace_free(kaamer_workspace *ws)
                      ws->d_pool_cursor, ws->d_lists, ws->d_list_counts, ws->d_status_out, ws->d_qinfo, ws->d_slots,
                      ws->d_slot_off, ws->d_group_first, ws->d_n_groups, ws->d_pos_words, ws->d_pos_base, ws->d_pos_off, ws->d_pos_bits, ws->d_g_keys,
                      ws->d_g_cnt, ws->d_g_min, ws->d_counter_replicas, ws->d_counters, ws->d_bsum, ws->d_chain, ws->d_sched, ws->d_n_sched, ws->d_group_start, ws->d_lay_total, ws->d_top_cnt, ws->d_top_pid, ws->d_top_km, ws->d_top_fp, ws->d_top_trim, ws->d_top_start, ws->d_top_size, ws->d_rep_flag, ws->d_rep_aalen, ws->d_rep_query, ws->d_rep_pid, ws->d_rep_km, ws->d_rep_fp, ws->d_rep_trim, ws->d_rep_rank, ws->d_rep_eoff, ws->d_rep_aoff, ws->d_rep_off, ws->d_rep_q, ws->d_rep_aa, ws->d_hit_off,
-                     ws->d_hit_pid, ws->d_hit_km, ws->d_hit_fp };
+                     ws->d_hit_pid, ws->d_hit_km, ws->d_hit_fp, ws->d_x_dst_off, ws->d_x_src_off, ws->d_x_nq_owned, ws->d_x_pid, ws->d_x_km, ws->d_x_fp, ws->d_x_ent_off };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (ws->ev) {
         for (hipEvent_t e : *ws->ev) (void)hipEventDestroy(e);
@@ -1196,7 +1205,9 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     ws->p_grid = ws->n_cu * p_per_cu;
     // a table has at most max(64, 3 x SizeInKmer) slots
     {
-        const uint64_t gc = ((uint64_t)GRP_MIN_TABLE * ws->q_cap + 3 * ws->pos_cap) / GRP_BUDGET + 4;
+        // (a merge counts partial entries instead of positions: as many as max_hits)
+        const uint64_t items = ws->pos_cap > ws->hit_cap ? ws->pos_cap : ws->hit_cap;
+        const uint64_t gc = ((uint64_t)GRP_MIN_TABLE * ws->q_cap + 3 * items) / GRP_BUDGET + 4;
         ws->groups_cap = (uint32_t)(gc > 0x7FFFFFFFull ? 0x7FFFFFFFull : gc);
     }
     int rc = KAAMER_OK;
@@ -1579,8 +1590,10 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     return KAAMER_OK;
 }
 
-int kaamer_merge_device(kaamer_workspace *ws, const uint64_t *d_ent_off, const uint32_t *d_pid, const uint32_t *d_km,
-                        const uint32_t *d_fp, uint32_t n_queries, uint64_t n_entries, void *stream, kaamer_device_result *out)
+// n_queries / n_entries are host-side bounds when d_n_queries (a device scalar) gives the actual number of queries
+static int merge_device_impl(kaamer_workspace *ws, const uint64_t *d_ent_off, const uint32_t *d_pid, const uint32_t *d_km,
+                             const uint32_t *d_fp, uint32_t n_queries, const uint32_t *d_n_queries, uint64_t n_entries, void *stream,
+                             kaamer_device_result *out)
 {
     if (!ws || !out || (n_queries && !d_ent_off) || (n_entries && (!d_pid || !d_km || !d_fp)))
         return kaamer_fail(KAAMER_E_ARG, "merge_device: bad argument");
@@ -1599,7 +1612,7 @@ int kaamer_merge_device(kaamer_workspace *ws, const uint64_t *d_ent_off, const u
     const uint32_t nq_bound = n_queries;
     const int pb = 256;
     hipLaunchKernelGGL(prep_merge_kernel, dim3((n_queries + pb - 1) / pb > 0 ? (n_queries + pb - 1) / pb : 1), dim3(pb), 0, s, d_ent_off,
-                       n_queries, ws->d_qinfo, ws->d_slots, ws->d_nq, ws->d_hit_off, ws->d_q_cnt);
+                       n_queries, d_n_queries, ws->d_qinfo, ws->d_slots, ws->d_nq, ws->d_hit_off, ws->d_q_cnt);
     launch_layout(ws, nq_bound, status, s);
     CountParams p;
     memset(&p, 0, sizeof p);
@@ -1650,16 +1663,160 @@ int kaamer_merge_device(kaamer_workspace *ws, const uint64_t *d_ent_off, const u
     return KAAMER_OK;
 }
 
+int kaamer_merge_device(kaamer_workspace *ws, const uint64_t *d_ent_off, const uint32_t *d_pid, const uint32_t *d_km,
+                        const uint32_t *d_fp, uint32_t n_queries, uint64_t n_entries, void *stream, kaamer_device_result *out)
+{
+    return merge_device_impl(ws, d_ent_off, d_pid, d_km, d_fp, n_queries, nullptr, n_entries, stream, out);
+}
+
+// ---- the exchange step of the sharded index (exchange.hip.inc) --------------------------------------
+int kaamer_exchange_layout_init(uint32_t world, uint32_t rank, uint32_t max_queries, uint64_t max_entries_per_peer,
+                                kaamer_exchange_layout *out)
+{
+    if (!out || world == 0 || rank >= world || max_entries_per_peer == 0 || max_entries_per_peer > 0xFFFFFFF0ull)
+        return kaamer_fail(KAAMER_E_ARG, "exchange_layout_init: bad argument");
+    memset(out, 0, sizeof *out);
+    out->world = world;
+    out->rank = rank;
+    out->q_cap = (max_queries + world - 1) / world + 1;
+    out->e_cap = (max_entries_per_peer + 3) & ~3ull;
+    out->block_words = (X_HDR + (uint64_t)out->q_cap + 3 * out->e_cap + 3) & ~3ull;
+    return KAAMER_OK;
+}
+
+static void x_fill(XParams &x, const kaamer_exchange_layout *L)
+{
+    memset(&x, 0, sizeof x);
+    x.world = L->world; x.rank = L->rank; x.q_cap = L->q_cap; x.e_cap = L->e_cap; x.block_words = L->block_words;
+}
+
+int kaamer_exchange_pack(kaamer_workspace *ws, const kaamer_exchange_layout *L, uint32_t *d_send, void *stream)
+{
+    if (!ws || !L || !d_send || L->world == 0) return kaamer_fail(KAAMER_E_ARG, "exchange_pack: bad argument");
+    if ((uint64_t)L->q_cap * L->world < ws->q_cap) return kaamer_fail(KAAMER_E_ARG, "exchange_pack: the layout holds fewer queries than the workspace");
+    HIPCHK(hipSetDevice(ws->device));
+    if (ws->x_world != L->world || ws->x_qcap != L->q_cap || !ws->d_x_dst_off) {
+        if (ws->d_x_dst_off) (void)hipFree(ws->d_x_dst_off);
+        ws->d_x_dst_off = nullptr;
+        const int rc = dev_alloc(&ws->d_x_dst_off, (size_t)L->world * L->q_cap);
+        if (rc) return rc;
+        ws->x_world = L->world; ws->x_qcap = L->q_cap;
+    }
+    XParams x;
+    x_fill(x, L);
+    x.d_nq = ws->d_nq;
+    x.hit_off = ws->compact ? ws->d_csr_off : ws->d_hit_off;
+    x.hit_cnt = ws->d_q_cnt;
+    x.pid = ws->compact ? ws->d_c_pid : ws->d_hit_pid;
+    x.km = ws->compact ? ws->d_c_km : ws->d_hit_km;
+    x.fp = ws->compact ? ws->d_c_fp : ws->d_hit_fp;
+    x.send = d_send;
+    x.dst_off = ws->d_x_dst_off;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(x_pack_scan_kernel, dim3(L->world), dim3(X_BLOCK), 0, s, x);
+    uint32_t gb = (ws->q_cap + 3) / 4;
+    if (gb > (uint32_t)ws->n_cu * 8) gb = (uint32_t)ws->n_cu * 8;
+    if (gb < 1) gb = 1;
+    hipLaunchKernelGGL(x_pack_copy_kernel, dim3(gb), dim3(256), 0, s, x);
+    HIPCHK(hipGetLastError());
+    return KAAMER_OK;
+}
+
+int kaamer_exchange_merge(kaamer_workspace *ws, const kaamer_exchange_layout *L, const uint32_t *d_recv, void *stream,
+                          kaamer_device_result *out)
+{
+    if (!ws || !L || !d_recv || !out || L->world == 0) return kaamer_fail(KAAMER_E_ARG, "exchange_merge: bad argument");
+    if (L->q_cap > ws->q_cap) return kaamer_fail(KAAMER_E_CAPACITY, "exchange_merge: %u owned queries exceed the merge workspace (%u)", L->q_cap, ws->q_cap);
+    const uint64_t m_cap = (uint64_t)L->world * L->e_cap;
+    if (m_cap > ws->hit_cap) return kaamer_fail(KAAMER_E_CAPACITY, "exchange_merge: %llu entries exceed the merge workspace's max_hits (%llu)",
+                                                 (unsigned long long)m_cap, (unsigned long long)ws->hit_cap);
+    HIPCHK(hipSetDevice(ws->device));
+    if (ws->x_world != L->world || ws->x_qcap != L->q_cap || ws->x_ecap != L->e_cap || !ws->d_x_src_off) {
+        void *bufs[] = { ws->d_x_src_off, ws->d_x_nq_owned, ws->d_x_pid, ws->d_x_km, ws->d_x_fp, ws->d_x_ent_off };
+        for (void *b : bufs) if (b) (void)hipFree(b);
+        ws->d_x_src_off = ws->d_x_nq_owned = ws->d_x_pid = ws->d_x_km = ws->d_x_fp = nullptr;
+        ws->d_x_ent_off = nullptr;
+        int rc = dev_alloc(&ws->d_x_src_off, (size_t)L->world * L->q_cap);
+        if (!rc) rc = dev_alloc(&ws->d_x_nq_owned, 1);
+        if (!rc) rc = dev_alloc(&ws->d_x_ent_off, (size_t)L->q_cap + 1);
+        if (!rc) rc = dev_alloc(&ws->d_x_pid, (size_t)m_cap);
+        if (!rc) rc = dev_alloc(&ws->d_x_km, (size_t)m_cap);
+        if (!rc) rc = dev_alloc(&ws->d_x_fp, (size_t)m_cap);
+        if (rc) return rc;
+        ws->x_world = L->world; ws->x_qcap = L->q_cap; ws->x_ecap = L->e_cap;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (!ws->clean) {  // the status word the unpack kernels may set must start from zero
+        HIPCHK(hipMemsetAsync(ws->d_pool_cursor, 0, (size_t)3 * CURSOR_STRIDE * sizeof(unsigned long long), s));
+        HIPCHK(hipMemsetAsync(ws->d_list_counts, 0, N_SMALL_SLOTS * sizeof(uint32_t), s));
+        HIPCHK(hipMemsetAsync(ws->d_counter_replicas, 0, sizeof(unsigned long long) * CTR_REPLICAS * CTR_N, s));
+        HIPCHK(hipMemsetAsync(ws->d_valid, 0, (size_t)(ws->pos_cap / 64 + 2) * sizeof(unsigned long long), s));
+        ws->clean = true;
+    }
+    XParams x;
+    x_fill(x, L);
+    x.recv = d_recv;
+    x.src_off = ws->d_x_src_off;
+    x.ent_off = ws->d_x_ent_off;
+    x.d_nq_owned = ws->d_x_nq_owned;
+    x.m_pid = ws->d_x_pid; x.m_km = ws->d_x_km; x.m_fp = ws->d_x_fp;
+    x.m_cap = m_cap;
+    x.status = ws->d_list_counts + SLOT_STATUS;
+    hipLaunchKernelGGL(x_unpack_scan_kernel, dim3(L->world + 1), dim3(X_BLOCK), 0, s, x);
+    uint32_t gb = (L->q_cap + 3) / 4;
+    if (gb > (uint32_t)ws->n_cu * 8) gb = (uint32_t)ws->n_cu * 8;
+    if (gb < 1) gb = 1;
+    hipLaunchKernelGGL(x_unpack_copy_kernel, dim3(gb), dim3(256), 0, s, x);
+    HIPCHK(hipGetLastError());
+    return merge_device_impl(ws, ws->d_x_ent_off, ws->d_x_pid, ws->d_x_km, ws->d_x_fp, L->q_cap, ws->d_x_nq_owned, m_cap, stream, out);
+}
+
+uint32_t kaamer_workspace_query_capacity(const kaamer_workspace *ws) { return ws ? ws->q_cap : 0u; }
+
+// grouped ncclSend / ncclRecv of equal blocks, for hosts that own an RCCL communicator and nothing else to drive it
+// (the library does not link RCCL: the symbols are looked up in the process at first use)
+int kaamer_rccl_alltoall(void *nccl_comm, const void *d_send, void *d_recv, uint64_t bytes_per_peer, uint32_t world, void *stream)
+{
+    typedef int (*grp_t)(void);
+    typedef int (*send_t)(const void *, size_t, int, int, void *, void *);
+    typedef int (*recv_t)(void *, size_t, int, int, void *, void *);
+    static grp_t g_start = nullptr, g_end = nullptr;
+    static send_t g_send = nullptr;
+    static recv_t g_recv = nullptr;
+    if (!nccl_comm || !d_send || !d_recv || world == 0) return kaamer_fail(KAAMER_E_ARG, "rccl_alltoall: bad argument");
+    if (!g_send) {
+        void *h = dlopen(nullptr, RTLD_NOW);
+        void *sym = h ? dlsym(h, "ncclSend") : nullptr;
+        if (!sym) { h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL); if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL); }
+        if (!h) return kaamer_fail(KAAMER_E_HIP, "rccl_alltoall: librccl is not loaded and cannot be opened");
+        g_start = (grp_t)dlsym(h, "ncclGroupStart"); g_end = (grp_t)dlsym(h, "ncclGroupEnd");
+        g_recv = (recv_t)dlsym(h, "ncclRecv");
+        g_send = (send_t)dlsym(h, "ncclSend");
+        if (!g_start || !g_end || !g_send || !g_recv) { g_send = nullptr; return kaamer_fail(KAAMER_E_HIP, "rccl_alltoall: RCCL symbols not found"); }
+    }
+    const int nccl_uint8 = 1;  // ncclUint8 (nccl.h: ncclInt8 = 0, ncclUint8 = 1)
+    int rc = g_start();
+    for (uint32_t peer = 0; peer < world && rc == 0; peer++) {
+        rc = g_send((const char *)d_send + (size_t)peer * bytes_per_peer, (size_t)bytes_per_peer, nccl_uint8, (int)peer, nccl_comm, stream);
+        if (rc == 0) rc = g_recv((char *)d_recv + (size_t)peer * bytes_per_peer, (size_t)bytes_per_peer, nccl_uint8, (int)peer, nccl_comm, stream);
+    }
+    const int rc2 = g_end();
+    if (rc || rc2) return kaamer_fail(KAAMER_E_HIP, "rccl_alltoall: RCCL error %d", rc ? rc : rc2);
+    return KAAMER_OK;
+}
+
 // FilterResults / top-N (and SetBestStartCodon for nucleotide input) of the workspace's last
 // search or merge, on the device; see topn.hip.inc.
 int kaamer_topn_device(kaamer_workspace *ws, const kaamer_topn_opts *opts, void *stream, kaamer_topn_result *out)
 {
     if (!ws || !opts || !out || opts->max_results < 1) return kaamer_fail(KAAMER_E_ARG, "topn_device: bad argument");
     const bool best_start = opts->best_start_codon != 0;
-    if (best_start && (!ws->nucleotide || ws->last_was_merge))
+    const kaamer_workspace *src = opts->orf_source ? opts->orf_source : ws;  // whose queries (ORFs) the results belong to
+    if (best_start && (!src->nucleotide || (ws->last_was_merge && !opts->orf_source)))
         return kaamer_fail(KAAMER_E_ARG, "topn_device: SetBestStartCodon needs the ORFs of a nucleotide/reads search");
-    if (ws->last_was_merge && !opts->d_size_in_kmer)
-        return kaamer_fail(KAAMER_E_ARG, "topn_device: merged results need d_size_in_kmer (the owner's queries)");
+    if (opts->orf_source && opts->orf_source->device != ws->device) return kaamer_fail(KAAMER_E_ARG, "topn_device: orf_source lives on another device");
+    if (ws->last_was_merge && !opts->d_size_in_kmer && !opts->orf_source)
+        return kaamer_fail(KAAMER_E_ARG, "topn_device: merged results need d_size_in_kmer or orf_source (the owner's queries)");
     if (best_start && !ws->firstpos) return kaamer_fail(KAAMER_E_ARG, "topn_device: SetBestStartCodon needs first positions (first_pos != 2)");
     HIPCHK(hipSetDevice(ws->device));
     if (ws->topn_k < opts->max_results) {
@@ -1682,15 +1839,17 @@ int kaamer_topn_device(kaamer_workspace *ws, const kaamer_topn_opts *opts, void 
     TopnParams p;
     memset(&p, 0, sizeof p);
     p.d_nq = ws->d_nq;
-    p.q = ws->d_q;
+    p.q = src->d_q;
+    p.q_first = opts->orf_source ? opts->q_first : 0u;
+    p.q_stride = opts->orf_source ? (opts->q_stride ? opts->q_stride : 1u) : 1u;
     p.size_in = opts->d_size_in_kmer;
     p.hit_cnt = ws->d_q_cnt;
     p.hit_off = ws->compact ? ws->d_csr_off : ws->d_hit_off;
     p.pid = ws->compact ? ws->d_c_pid : ws->d_hit_pid;
     p.km = ws->compact ? ws->d_c_km : ws->d_hit_km;
     p.fp = ws->compact ? ws->d_c_fp : ws->d_hit_fp;
-    p.orf_aa = ws->d_orf_aa;
-    p.starts_alt = ws->d_starts_alt;
+    p.orf_aa = src->d_orf_aa;
+    p.starts_alt = src->d_starts_alt;
     p.min_k_ratio = opts->min_k_ratio;
     p.min_k_match = opts->min_k_match;
     p.K = opts->max_results;
@@ -1726,6 +1885,7 @@ int kaamer_workspace_finish(kaamer_workspace *ws, void *stream, kaamer_counters 
     if (status & ST_CHAIN_TIMEOUT) return kaamer_fail(KAAMER_E_HIP, "table layout: a tile never published its total");
     if (status & (ST_QUERY_CAP | ST_AA_CAP))
         return kaamer_fail(KAAMER_E_CAPACITY, "more ORFs than the workspace holds: raise workspace max_queries (now %u)", ws->q_cap);
+    if (status & ST_EXCHANGE_CAP) return kaamer_fail(KAAMER_E_CAPACITY, "exchange block capacity exceeded: raise max_entries_per_peer / max_queries of the exchange layout");
     if (status & ST_POS_CAP) return kaamer_fail(KAAMER_E_CAPACITY, "position bitmaps exceed the workspace: raise max_pos_words (now %llu)", (unsigned long long)ws->bits_cap);
     if (status & ST_G_ARENA_FULL)
         return kaamer_fail(KAAMER_E_CAPACITY, "global counting arena exhausted: raise workspace g_tier_slots (now %llu)", (unsigned long long)ws->g_slots);

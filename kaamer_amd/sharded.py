@@ -8,13 +8,19 @@ xGMI: every rank talks to every other rank at once, all seven links busy — not
 moves each partial list to its owner, and the owner merges them on the device
 (`kaamer_merge_device`: integer sums, so the result is bit-identical to the one-GPU path).
 
-Everything here is plumbing: index arithmetic on torch tensors and `torch.distributed`
-calls; the search and the merge are the C-ABI kernels.  The exchange helpers are
-device-agnostic so the N>1 path is testable with the gloo backend on CPU.
+The product path is `ShardedSearcher`: C-ABI calls only (search, kaamer_exchange_pack,
+kaamer_exchange_merge, kaamer_topn_device) around ONE collective, no host synchronisation.
+The torch functions before it (`build_send`, `exchange`, `to_query_major`) are a
+device-agnostic restatement of the same routing with variable-size messages: they let the
+N>1 routing be tested with the gloo backend on CPU, where no kernel can run.
 """
+import ctypes as C
+
 import numpy as np
 import torch
 import torch.distributed as dist
+
+from . import abi, api
 
 
 def owner_perm(nq, world, device):
@@ -106,28 +112,46 @@ def dev_tensor(ptr, n, dtype):
 
 
 class ShardedSearcher:
-    """rank-local driver: search my shard, exchange, merge my queries"""
+    """Rank-local driver of the sharded index: search my shard, pack, all-to-all, merge my queries, post-steps.
+    Every step is a C-ABI call enqueued on one stream (kaamer_search_device, kaamer_exchange_pack,
+    kaamer_exchange_merge, kaamer_topn_device); the transport is torch.distributed's all_to_all_single on
+    the packed blocks with EQUAL splits (backend nccl = RCCL: grouped send/recv over xGMI), so a step has no
+    host synchronisation at all.  Works for protein and for nucleotide / reads input (every rank translates;
+    the owner's post-steps use its own ORFs: orf_source)."""
 
-    def __init__(self, index, search_ws, merge_ws, rank, world, group=None):
-        self.index, self.ws, self.mws = index, search_ws, merge_ws
-        self.rank, self.world, self.group = rank, world, group
+    def __init__(self, index, rank, world, max_seq_bytes, max_seqs, seq_type=abi.PROTEIN, max_entries_per_peer=1 << 20,
+                 group=None, max_hits=0, g_tier_slots=0):
+        self.index, self.rank, self.world, self.group = index, rank, world, group
+        self.nucl = seq_type in (abi.READS, abi.NUCLEOTIDE)
+        self.ws = api.Workspace(index, max_seq_bytes, max_seqs, seq_type=seq_type, first_pos=1, max_hits=max_hits,
+                                g_tier_slots=g_tier_slots)
+        self.layout = abi.ExchangeLayout()
+        abi.check(abi.lib().kaamer_exchange_layout_init(world, rank, self.ws.query_capacity, max_entries_per_peer,
+                                                        C.byref(self.layout)))
+        L = self.layout
+        self.mws = api.Workspace(index, 64, L.q_cap, max_queries=L.q_cap, first_pos=1, max_hits=world * L.e_cap,
+                                 g_tier_slots=g_tier_slots)
+        n = world * int(L.block_words)
+        self.send = torch.empty(n, dtype=torch.int32, device="cuda")
+        self.recv = torch.empty(n, dtype=torch.int32, device="cuda") if world > 1 else self.send
 
-    def step(self, d_buf, d_off, n_seqs, seq_bytes, stream):
-        """-> (ent_off, merged DeviceResult, counters of the local search)"""
-        r = self.ws.search_device(d_buf.data_ptr(), d_off.data_ptr(), n_seqs, seq_bytes, stream=stream)
-        c = self.ws.finish(stream)
-        cap = int(r.hit_capacity)  # the lists sit where the counting kernel put them (hit_off, hit_cnt)
-        hit_off = dev_tensor(r.d_hit_off, n_seqs, torch.int64)
-        hit_cnt = dev_tensor(r.d_hit_cnt, n_seqs, torch.int32)
-        pid = dev_tensor(r.d_hit_pid, cap, torch.int32)
-        km = dev_tensor(r.d_hit_kmatch, cap, torch.int32)
-        fp = dev_tensor(r.d_hit_first_pos, cap, torch.int32)
-        cnt_p, ents, qs, es = build_send(hit_off, hit_cnt, pid, km, fp, self.world)
-        recv_cnt, recv_ents = exchange(cnt_p, ents, qs, es, self.rank, self.world, self.group)
-        ent_off, q_ents = to_query_major(recv_cnt, recv_ents)
-        cols = [q_ents[:, i].contiguous() for i in range(3)] if q_ents.numel() else \
-            [torch.zeros(1, dtype=torch.int32, device=ents.device)] * 3
-        self._keep = (ent_off, cols)  # alive until the merge kernels have run
-        m = self.mws.merge_device(ent_off.data_ptr(), cols[0].data_ptr(), cols[1].data_ptr(), cols[2].data_ptr(),
-                                  ent_off.numel() - 1, int(q_ents.shape[0]), stream=stream)
-        return ent_off, m, c
+    def step(self, d_seqs_ptr, d_off_ptr, n_seqs, seq_bytes, stream):
+        """`stream`: a torch.cuda.Stream (the collective is issued under it).  -> DeviceResult of the merged,
+        owned queries (query i of the result = query rank + i * world of the batch)"""
+        raw = stream.cuda_stream
+        self.ws.search_device(d_seqs_ptr, d_off_ptr, n_seqs, seq_bytes, stream=raw)
+        self.ws.exchange_pack(self.layout, self.send.data_ptr(), raw)
+        if self.world > 1:
+            with torch.cuda.stream(stream):
+                dist.all_to_all_single(self.recv, self.send, group=self.group)
+        return self.mws.exchange_merge(self.layout, self.recv.data_ptr(), raw)
+
+    def topn(self, stream, min_k_ratio=0.05, min_k_match=10, max_results=10):
+        """the post-steps of the reference's drivers on the merged results (SetBestStartCodon for nucleotide input)"""
+        return self.mws.topn_device(min_k_ratio, min_k_match, max_results, best_start_codon=self.nucl,
+                                    orf_source=self.ws, q_first=self.rank, q_stride=self.world, stream=stream.cuda_stream)
+
+    def finish(self, stream):
+        """-> (counters of the local search, counters of the merge); raises on a capacity overflow"""
+        c = self.ws.finish(stream.cuda_stream)
+        return c, self.mws.finish(stream.cuda_stream)

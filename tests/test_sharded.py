@@ -76,14 +76,81 @@ def _gloo_worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-def test_exchange_gloo_world2(klib, oracle):
+def _gloo_worker_reads(rank, world, port, ret):
+    """reads over two shards: every rank translates, searches its shard, one exchange by ORF owner, merge, then the
+    reference's post-steps (sortMapByValue, SetBestStartCodon, FilterResults: the product's host entry points) --
+    against the oracle on the whole database"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    from kaamer_amd import abi, sharded, workload
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        klib = abi.lib()
+        db = workload.make_db(80, seed=3)
+        reads = workload.unpack(workload.make_reads(db, 40, seed=5))
+        orfs = [o for r in reads for o in O.get_orfs(r)]          # every rank translates: same ORFs, same order
+        k, i = _shard_pairs(klib, O, db, rank, world)
+        oix = O.Index.from_pairs(k, i)
+        off, pid, km, fp = (torch.from_numpy(x) for x in _partial_csr_orfs(O, oix, orfs))
+        cnt_p, ents, qs, es = sharded.build_send(off, (off[1:] - off[:-1]).to(torch.int32), pid, km, fp, world)
+        recv_cnt, recv_ents = sharded.exchange(cnt_p, ents, qs, es, rank, world)
+        ent_off, q_ents = sharded.to_query_major(recv_cnt, recv_ents)
+        merged = _numpy_merge(ent_off.numpy(), q_ents.numpy())
+        full = O.Index.from_proteins(None, packed=db)
+        owned = list(range(rank, len(orfs), world))
+        assert len(merged) == len(owned)
+        n = 0
+        for j, q in enumerate(owned):
+            o = orfs[q]
+            exp_full, exp_rep = _oracle_report(O, full, o, True)
+            assert merged[j] == exp_full, (rank, q)
+            # post-steps on the merged list, host entry points of the product library
+            ids = np.array(sorted(merged[j]), np.uint32)
+            kms = np.array([merged[j][int(p)][0] for p in ids], np.uint32)
+            fps = np.array([merged[j][int(p)][1] for p in ids], np.uint32)
+            order = np.zeros(len(ids), np.uint32)
+            klib.kaamer_sort_hits(ids.ctypes.data, kms.ctypes.data, len(ids), order.ctypes.data)
+            ids, kms, fps = ids[order], kms[order], fps[order]
+            keep = 0
+            if len(kms) and kms[0] >= 10:                      # search_fastq.go:119
+                sa = np.array(o["starts"], np.int32)
+                aa = o["seq"].encode("latin-1")
+                sp, sz = C.c_int32(o["start"]), C.c_int32(O.size_in_kmer(o["seq"]))
+                klib.kaamer_set_best_start_codon(kms.ctypes.data, fps.ctypes.data, len(kms), sa.ctypes.data, len(sa), int(o["plus"]),
+                                                 aa, len(aa), C.byref(sp), C.byref(sz))
+                keep = int(klib.kaamer_filter_results(kms.ctypes.data, len(kms), sz.value, 0.05, 10, 10))
+            assert list(zip(ids[:keep].tolist(), kms[:keep].tolist())) == exp_rep, (rank, q)
+            n += len(exp_full)
+        ret[rank] = n
+    finally:
+        dist.destroy_process_group()
+
+
+def _partial_csr_orfs(oracle, oix, orfs):
+    off, pid, km, fp = [0], [], [], []
+    for o in orfs:
+        p, k, pos = oix.search(o["seq"], want_positions=True)
+        pid += p.tolist(); km += k.tolist(); fp += [int(np.argmax(pos[i])) for i in range(len(p))]
+        off.append(len(pid))
+    return (np.array(off, np.int64), np.array(pid, np.int32), np.array(km, np.int32), np.array(fp, np.int32))
+
+
+@pytest.mark.parametrize("worker", ["protein", "reads"])
+def test_exchange_gloo_world2(klib, oracle, worker):
     import torch.multiprocessing as mp
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
+    target = _gloo_worker if worker == "protein" else _gloo_worker_reads
     with ctx.Manager() as mgr:
         ret = mgr.dict()
-        procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, ret)) for r in range(2)]
+        procs = [ctx.Process(target=target, args=(r, 2, port, ret)) for r in range(2)]
         for p in procs:
             p.start()
         for p in procs:
@@ -113,6 +180,110 @@ def test_exchange_helpers_single_process():
     ent_off, q_ents = sharded.to_query_major(recv_cnt, recv)
     exp = torch.cat([pid[off[q]:off[q + 1]] for q in range(1, nq, world)])
     assert torch.equal(q_ents[:, 0], exp) and ent_off[-1] == len(exp)
+
+
+def _route(sends, layouts, d):
+    """what rank d receives: block s = the block rank s packed for rank d (an all-to-all with equal splits)"""
+    import torch
+    bw = int(layouts[0].block_words)
+    return torch.cat([sends[s][d * bw:(d + 1) * bw] for s in range(len(sends))])
+
+
+def _oracle_report(oracle, oix, orf, reads):
+    """the reference's per-query block on the WHOLE database: (hit map with first positions, reported hits)"""
+    if reads:
+        seq, starts, plus, start = orf["seq"], orf["starts"], orf["plus"], orf["start"]
+    else:
+        seq = orf
+    size = oracle.size_in_kmer(seq)
+    if size < 7 and not reads:
+        return {}, []
+    pid, km, pos = oix.search(seq, want_positions=True)
+    full = {int(p): (int(k), int(np.argmax(pos[i]))) for i, (p, k) in enumerate(zip(pid, km))}
+    keep = 0
+    if reads:
+        if len(km) and km[0] >= 10:
+            _, _, size = oracle.set_best_start_codon(km, pos, size, starts, plus, seq, start)
+            keep = oracle.filter_results(km, size)
+    elif len(km):
+        keep = oracle.filter_results(km, size)
+    return full, list(zip(pid[:keep].tolist(), km[:keep].tolist()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("reads", [False, True])
+def test_sharded_through_the_c_abi(klib, oracle, gpu_device, reads):
+    """W = 2 shards on one GPU, every step through the C ABI: search each shard, kaamer_exchange_pack, route the
+    blocks as the all-to-all would, kaamer_exchange_merge on each owner, kaamer_topn_device with orf_source --
+    for protein queries and for reads (every rank translates; SetBestStartCodon on the owner).  Also W = 1
+    (send buffer = receive buffer), which must reproduce the unsharded results."""
+    import ctypes as C
+    import torch
+    from kaamer_amd import abi, api, sharded, workload
+    db = workload.make_db(600, seed=6)
+    full = oracle.Index.from_proteins(None, packed=db)
+    if reads:
+        q = workload.make_reads(db, 300, seed=12)
+        rl = workload.unpack(q)
+        queries = [o for r in rl for o in oracle.get_orfs(r)]
+        seq_type = abi.READS
+    else:
+        seqs = workload.unpack(workload.make_protein_queries(db, 150, seed=7)) + [max(workload.unpack(db), key=len), b"AAAAAAA", b""]
+        q = api.pack_sequences(seqs)
+        queries = seqs
+        seq_type = abi.PROTEIN
+    buf, offs = q
+    n_seqs = len(offs) - 1
+    d_buf = torch.from_numpy(buf).cuda()
+    d_off = torch.from_numpy(offs.view(np.int64)).cuda()
+    st = torch.cuda.current_stream()
+    exp = [_oracle_report(oracle, full, x, reads) for x in queries]
+    for world in (1, 2):
+        ranks = []
+        for r in range(world):
+            ix = api.Index.from_image(api.Image.from_proteins(packed=db, shard=r, n_shards=world), gpu_device)
+            ranks.append((ix, sharded.ShardedSearcher(ix, r, world, len(buf), n_seqs, seq_type=seq_type, max_entries_per_peer=1 << 16)))
+        # search + pack on every "rank" (the searcher's own step() does the same, then the collective)
+        for ix, ss in ranks:
+            ss.ws.search_device(d_buf.data_ptr(), d_off.data_ptr(), n_seqs, len(buf), stream=st.cuda_stream)
+            ss.ws.exchange_pack(ss.layout, ss.send.data_ptr(), st.cuda_stream)
+            c = ss.ws.finish(st.cuda_stream)
+            assert c["n_queries"] == (len(queries) if reads else sum(1 for x in queries if oracle.size_in_kmer(x) >= 7))
+        n_checked = 0
+        for d, (ix, ss) in enumerate(ranks):
+            recv = _route([x[1].send for x in ranks], [x[1].layout for x in ranks], d)
+            m = ss.mws.exchange_merge(ss.layout, recv.data_ptr(), st.cuda_stream)
+            t = ss.topn(st)
+            c = ss.mws.finish(st.cuda_stream)
+            owned = list(range(d, len(queries), world))
+            hit_off = sharded.dev_tensor(m.d_hit_off, len(owned), torch.int64).cpu().numpy()
+            hit_cnt = sharded.dev_tensor(m.d_hit_cnt, len(owned), torch.int32).cpu().numpy()
+            nh = int(m.hit_capacity)
+            assert int(hit_cnt.sum()) == c["n_hits"]
+            pid = sharded.dev_tensor(m.d_hit_pid, nh, torch.int32).cpu().numpy().view(np.uint32)
+            km = sharded.dev_tensor(m.d_hit_kmatch, nh, torch.int32).cpu().numpy()
+            fp = sharded.dev_tensor(m.d_hit_first_pos, nh, torch.int32).cpu().numpy()
+            tc = sharded.dev_tensor(t.d_top_cnt, len(owned), torch.int32).cpu().numpy()
+            tp = sharded.dev_tensor(t.d_top_pid, len(owned) * 10, torch.int32).cpu().numpy().view(np.uint32).reshape(-1, 10)
+            tk = sharded.dev_tensor(t.d_top_kmatch, len(owned) * 10, torch.int32).cpu().numpy().reshape(-1, 10)
+            for j, qi in enumerate(owned):
+                a, b = int(hit_off[j]), int(hit_off[j]) + int(hit_cnt[j])
+                got = {int(x): (int(y), int(z)) for x, y, z in zip(pid[a:b], km[a:b], fp[a:b])}
+                assert got == exp[qi][0], (world, d, qi)
+                k = len(exp[qi][1])
+                assert int(tc[j]) == k, (world, d, qi)
+                assert list(zip(tp[j, :k].tolist(), tk[j, :k].tolist())) == exp[qi][1], (world, d, qi)
+                n_checked += len(got)
+        assert n_checked > 500
+    # a block too small for the partial lists is reported, never a partial result
+    ix, ss = ranks[0]
+    small = sharded.ShardedSearcher(ix, 0, 2, len(buf), n_seqs, seq_type=seq_type, max_entries_per_peer=64)
+    small.ws.search_device(d_buf.data_ptr(), d_off.data_ptr(), n_seqs, len(buf), stream=st.cuda_stream)
+    small.ws.exchange_pack(small.layout, small.send.data_ptr(), st.cuda_stream)
+    small.mws.exchange_merge(small.layout, small.send.data_ptr(), st.cuda_stream)
+    with pytest.raises(abi.KaamerError) as e:
+        small.mws.finish(st.cuda_stream)
+    assert e.value.code == abi.E_CAPACITY
 
 
 @pytest.mark.gpu
