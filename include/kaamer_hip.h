@@ -100,6 +100,50 @@ void kaamer_image_free(kaamer_image *img);
 uint32_t kaamer_image_get(const kaamer_image *img, uint32_t key, uint32_t *ids, uint32_t cap);
 
 /* ------------------------------------------------------------------------- */
+/* makedb — which proteins a database file contributes and under which ids      */
+/* (pkg/makedb/inputFASTA.go:95-124,191-250; inputTSV.go:92-142), kept with     */
+/* their annotations: the table FetchHitsInformation reads                      */
+/* (pkg/search/search.go:454-470, pkg/kvstore/protein.proto) instead of one     */
+/* ProteinStore point read per hit.  Text is taken already decompressed.        */
+/*   FASTA: record k (1-based) gets id k+1, the last two records share id N     */
+/*          (reference behaviour); names with ", partial" and sequences shorter */
+/*          than 7 are dropped; sequences are upper-cased; feature: ProteinName */
+/*   TSV:   header row with EntryID and Sequence columns (any case); accepted   */
+/*          rows get 0-based ids; sequences are NOT upper-cased; every other    */
+/*          column is a feature                                                 */
+/* ------------------------------------------------------------------------- */
+typedef struct kaamer_proteins kaamer_proteins;
+int kaamer_makedb_fasta(const char *text, uint64_t len, kaamer_proteins **out);
+int kaamer_makedb_tsv(const char *text, uint64_t len, kaamer_proteins **out);
+uint32_t kaamer_proteins_count(const kaamer_proteins *p);           /* accepted proteins       */
+const uint32_t *kaamer_proteins_ids(const kaamer_proteins *p);      /* their protein ids       */
+const uint8_t *kaamer_proteins_seqs(const kaamer_proteins *p);      /* packed sequences        */
+const uint64_t *kaamer_proteins_offsets(const kaamer_proteins *p);  /* count + 1               */
+uint32_t kaamer_proteins_n_features(const kaamer_proteins *p);      /* KStats.Features         */
+const char *kaamer_proteins_feature_name(const kaamer_proteins *p, uint32_t i);
+void kaamer_proteins_stats(const kaamer_proteins *p, uint64_t out[3]); /* KStats: NumberOfProteins, NumberOfAA, NumberOfKmers */
+int kaamer_proteins_save(const kaamer_proteins *p, const char *path);
+int kaamer_proteins_load(const char *path, kaamer_proteins **out);
+void kaamer_proteins_free(kaamer_proteins *p);
+/* emit loops + indexdb collapse over the accepted proteins under their ids -> one shard's image */
+int kaamer_image_build_makedb(const kaamer_proteins *p, uint32_t shard, uint32_t n_shards, double load_factor,
+                              kaamer_image **out);
+/* One Protein entry (protein.proto).  Pointers go into the table and stay valid until it is freed;
+ * feature i is features[feature_off[i] .. feature_off[i+1]). */
+typedef struct {
+    uint32_t found;             /* 0: no protein under this id (entry zeroed) */
+    uint32_t length;            /* Protein.Length                              */
+    const char *entry_id;       /* Protein.EntryId, entry_id_len bytes         */
+    uint32_t entry_id_len;
+    uint32_t n_features;
+    const uint8_t *sequence;    /* Protein.Sequence, length bytes              */
+    const char *features;
+    const uint64_t *feature_off; /* n_features + 1                             */
+} kaamer_protein_entry;
+/* FetchHitsInformation (search.go:454-470) for n protein ids at once */
+int kaamer_fetch_hits(const kaamer_proteins *p, const uint32_t *ids, uint32_t n, kaamer_protein_entry *out);
+
+/* ------------------------------------------------------------------------- */
 /* Index handle — replaces the read side of kvstore.KVStoresNew               */
 /* (kv_stores.go:46-104) and KVStore.GetValueFromBadger (kv_store.go:179-204): */
 /* the table lives in the HBM of one device.                                   */

@@ -96,6 +96,11 @@ class BatchTop(C.Structure):
                 ("orf_aa", C.POINTER(C.c_uint8)), ("counters", Counters)]
 
 
+class ProteinEntry(C.Structure):
+    _fields_ = [("found", C.c_uint32), ("length", C.c_uint32), ("entry_id", C.c_void_p), ("entry_id_len", C.c_uint32),
+                ("n_features", C.c_uint32), ("sequence", C.c_void_p), ("features", C.c_void_p), ("feature_off", C.POINTER(C.c_uint64))]
+
+
 class TopnResult(C.Structure):
     _fields_ = [("max_results", C.c_uint32), ("d_top_cnt", C.c_void_p), ("d_top_pid", C.c_void_p),
                 ("d_top_kmatch", C.c_void_p), ("d_top_first_pos", C.c_void_p), ("d_trim", C.c_void_p),
@@ -117,6 +122,20 @@ SYMBOLS = {
     "kaamer_image_get_stats": (C.c_int, [C.c_void_p, C.POINTER(ImageStats)]),
     "kaamer_image_free": (None, [C.c_void_p]),
     "kaamer_image_get": (C.c_uint32, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]),
+    "kaamer_makedb_fasta": (C.c_int, [C.c_char_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "kaamer_makedb_tsv": (C.c_int, [C.c_char_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "kaamer_proteins_count": (C.c_uint32, [C.c_void_p]),
+    "kaamer_proteins_ids": (C.POINTER(C.c_uint32), [C.c_void_p]),
+    "kaamer_proteins_seqs": (C.POINTER(C.c_uint8), [C.c_void_p]),
+    "kaamer_proteins_offsets": (C.POINTER(C.c_uint64), [C.c_void_p]),
+    "kaamer_proteins_n_features": (C.c_uint32, [C.c_void_p]),
+    "kaamer_proteins_feature_name": (C.c_char_p, [C.c_void_p, C.c_uint32]),
+    "kaamer_proteins_stats": (None, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "kaamer_proteins_save": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "kaamer_proteins_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "kaamer_proteins_free": (None, [C.c_void_p]),
+    "kaamer_image_build_makedb": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_double, C.POINTER(C.c_void_p)]),
+    "kaamer_fetch_hits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(ProteinEntry)]),
     "kaamer_index_open_image": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "kaamer_index_open": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
     "kaamer_index_close": (None, [C.c_void_p]),

@@ -86,6 +86,98 @@ class Image:
             pass
 
 
+class Proteins:
+    """What makedb accepts from a database file (ids, sequences, annotations): kaamer_makedb_fasta / _tsv
+    (pkg/makedb/inputFASTA.go, inputTSV.go) and the table kaamer_fetch_hits reads (search.go:454-470)."""
+
+    def __init__(self, handle):
+        self._h = C.c_void_p(handle)
+
+    @classmethod
+    def _make(cls, fn, text):
+        text = bytes(text)
+        h = C.c_void_p()
+        abi.check(fn(text, len(text), C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def from_fasta(cls, text):
+        return cls._make(abi.lib().kaamer_makedb_fasta, text)
+
+    @classmethod
+    def from_tsv(cls, text):
+        return cls._make(abi.lib().kaamer_makedb_tsv, text)
+
+    @classmethod
+    def load(cls, path):
+        h = C.c_void_p()
+        abi.check(abi.lib().kaamer_proteins_load(str(path).encode(), C.byref(h)))
+        return cls(h.value)
+
+    def save(self, path):
+        abi.check(abi.lib().kaamer_proteins_save(self._h, str(path).encode()))
+
+    def __len__(self):
+        return abi.lib().kaamer_proteins_count(self._h)
+
+    @property
+    def ids(self):
+        n = len(self)
+        return np.ctypeslib.as_array(abi.lib().kaamer_proteins_ids(self._h), shape=(n,)).copy() if n else np.zeros(0, np.uint32)
+
+    @property
+    def packed(self):
+        n = len(self)
+        offs = np.ctypeslib.as_array(abi.lib().kaamer_proteins_offsets(self._h), shape=(n + 1,)).copy()
+        buf = np.ctypeslib.as_array(abi.lib().kaamer_proteins_seqs(self._h), shape=(int(offs[-1]),)).copy() \
+            if offs[-1] else np.zeros(0, np.uint8)
+        return buf, offs
+
+    @property
+    def feature_names(self):
+        L = abi.lib()
+        return [L.kaamer_proteins_feature_name(self._h, i) for i in range(L.kaamer_proteins_n_features(self._h))]
+
+    def stats(self):
+        out = (C.c_uint64 * 3)()
+        abi.lib().kaamer_proteins_stats(self._h, out)
+        return dict(NumberOfProteins=out[0], NumberOfAA=out[1], NumberOfKmers=out[2], Features=self.feature_names)
+
+    def image(self, shard=0, n_shards=1, load_factor=0.5):
+        h = C.c_void_p()
+        abi.check(abi.lib().kaamer_image_build_makedb(self._h, shard, n_shards, load_factor, C.byref(h)))
+        return Image(h.value)
+
+    def fetch_hits(self, ids):
+        """[None | dict(EntryId, Sequence, Length, Features)] per protein id (protein.proto)"""
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        ent = (abi.ProteinEntry * max(1, len(ids)))()
+        abi.check(abi.lib().kaamer_fetch_hits(self._h, ids.ctypes.data, len(ids), ent))
+        names = self.feature_names
+        out = []
+        for e in ent[:len(ids)]:
+            if not e.found:
+                out.append(None)
+                continue
+            fo = [e.feature_off[i] for i in range(e.n_features + 1)]
+            blob = C.string_at(e.features + fo[0], fo[-1] - fo[0]) if fo[-1] > fo[0] else b""
+            out.append(dict(EntryId=C.string_at(e.entry_id, e.entry_id_len), Sequence=C.string_at(e.sequence, e.length),
+                            Length=e.length,
+                            Features={names[i]: blob[fo[i] - fo[0]:fo[i + 1] - fo[0]] for i in range(e.n_features)}))
+        return out
+
+    def close(self):
+        if self._h:
+            abi.lib().kaamer_proteins_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def build_image_from_proteins(seqs, ids=None, **kw):
     return Image.from_proteins(seqs, ids=ids, **kw)
 

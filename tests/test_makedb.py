@@ -1,0 +1,164 @@
+"""makedb acceptance and id rules (pkg/makedb/inputFASTA.go, inputTSV.go) and the protein table behind
+FetchHitsInformation (search.go:454-470), against the oracle's literal restatement.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from kaamer_amd import abi, api
+
+
+def _makedb_ref():
+    from oracle import makedb_ref
+    return makedb_ref
+
+
+def _pairs_of(records, oracle):
+    """what the reference's KmerStore ends up with: {key -> sorted distinct ids} as (keys, ids) arrays"""
+    oix = oracle.Index.from_proteins([r[2] for r in records], ids=np.array([r[0] for r in records], np.uint32))
+    return oix
+
+
+def _image_pairs(img, oix):
+    pr = oix.pairs()                       # (key << 32 | id), sorted, distinct
+    keys, ids = (pr >> np.uint64(32)).astype(np.uint32), (pr & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    last = None
+    for k in np.unique(keys):
+        got = img.get(int(k))
+        exp = np.unique(ids[keys == k])
+        assert got.tolist() == exp.tolist(), hex(int(k))
+        last = k
+    assert img.stats()["n_keys"] == len(np.unique(keys))
+    return last
+
+
+FASTA = b""">sp|P1|A first protein OS=Somewhere
+MKTAYIAKQR
+qistfvkshf
+>sp|P2|B hypothetical protein, partial
+MKTAYIAKQRQISTFVKSHFSRQ
+>P3
+MKTAY
+>P4 lower case and a dot
+mktayiakqr.istfvk\r
+>P5 two from the end
+ACDEFGHIKLMNPQRSTVWY
+>P6 the last record shares its id with P5
+YWVTSRQPNMLKIHGFEDCA
+"""
+
+
+def test_fasta_rules_match_the_reference(klib, oracle):
+    ref = _makedb_ref().run_fasta(FASTA)
+    # the id quirk itself: record k -> k + 1, the last two share N (inputFASTA.go:98-124)
+    assert [(r[0], r[1]) for r in ref] == [(2, b"sp|P1|A"), (5, b"P4"), (6, b"P5"), (6, b"P6")]
+    p = api.Proteins.from_fasta(FASTA)
+    buf, offs = p.packed
+    got = [(int(i), bytes(buf[int(offs[j]):int(offs[j + 1])])) for j, i in enumerate(p.ids)]
+    assert got == [(r[0], r[2]) for r in ref]
+    assert got[0][1] == b"MKTAYIAKQRQISTFVKSHF" and got[1][1] == b"MKTAYIAKQR.ISTFVK"
+    assert p.feature_names == [b"ProteinName"]
+    st = p.stats()
+    assert (st["NumberOfProteins"], st["NumberOfAA"]) == (4, sum(len(r[2]) for r in ref))
+    assert st["NumberOfKmers"] == sum(len(r[2]) - 6 for r in ref)
+    img = p.image()
+    _image_pairs(img, _pairs_of(ref, oracle))
+    # FetchHitsInformation: id 6 holds the LAST record written under it (ProteinStore overwrite)
+    e = p.fetch_hits([2, 6, 5, 3, 99])
+    assert e[3] is None and e[4] is None
+    assert e[0] == dict(EntryId=b"sp|P1|A", Sequence=b"MKTAYIAKQRQISTFVKSHF", Length=20,
+                        Features={b"ProteinName": b"first protein OS=Somewhere"})
+    assert e[1]["EntryId"] == b"P6" and e[1]["Sequence"] == b"YWVTSRQPNMLKIHGFEDCA"
+    assert e[2]["Features"] == {b"ProteinName": b"lower case and a dot"}
+
+
+def test_fasta_text_before_the_first_header_and_no_final_newline(klib, oracle):
+    text = b"ACDEFGHIKLMN\n>A x\nMKTAYIAKQR\n>B y\nMKTAYIAKQRQISTFVK"
+    ref = _makedb_ref().run_fasta(text)
+    assert [(r[0], r[1], r[2]) for r in ref] == [(1, b"", b"ACDEFGHIKLMN"), (2, b"A", b"MKTAYIAKQR"), (2, b"B", b"MKTAYIAKQRQISTFVK")]
+    p = api.Proteins.from_fasta(text)
+    assert p.ids.tolist() == [1, 2, 2]
+    _image_pairs(p.image(), _pairs_of(ref, oracle))
+    assert len(api.Proteins.from_fasta(b"")) == 0 and len(api.Proteins.from_fasta(b">only a header\n")) == 0
+
+
+TSV = b"""EntryID\tOrganism\tSEQUENCE\tEC
+P1\tE. coli\tMKTAYIAKQRQISTFVK\t1.1.1.1
+\tno id\tMKTAYIAKQRQISTFVK\t-
+P3\tshort\tMKTAY\t-
+P4\tlower stays lower\tmktayiakqrqistfvk\t2.7.7.7
+P5\tshort row\tACDEFGHIKLMNPQRSTVWY
+P6\textra\tYWVTSRQPNMLKIHGFEDCA\t3.3.3.3\tignored
+"""
+
+
+def test_tsv_rules_match_the_reference(klib, oracle):
+    ref = _makedb_ref().run_tsv(TSV)
+    assert [(r[0], r[1]) for r in ref] == [(0, b"P1"), (1, b"P4"), (2, b"P5"), (3, b"P6")]   # 0-based over ACCEPTED rows
+    p = api.Proteins.from_tsv(TSV)
+    buf, offs = p.packed
+    got = [(int(i), bytes(buf[int(offs[j]):int(offs[j + 1])])) for j, i in enumerate(p.ids)]
+    assert got == [(r[0], r[2]) for r in ref]
+    assert got[1][1] == b"mktayiakqrqistfvk"            # no ToUpper on the TSV path: its k-mers encode to 0s
+    assert p.feature_names == [b"Organism", b"EC"]
+    _image_pairs(p.image(), _pairs_of(ref, oracle))
+    ents = p.fetch_hits([r[0] for r in ref])
+    for e, r in zip(ents, ref):
+        assert (e["EntryId"], e["Sequence"], e["Length"], e["Features"]) == (r[1], r[2], len(r[2]), r[3])
+    assert ents[2]["Features"] == {b"Organism": b"short row", b"EC": b""}
+    for bad, msg in ((b"Name\tSequence\nx\tMKTAYIAKQR\n", "EntryID"), (b"entryid\tseq\nx\tMKTAYIAKQR\n", "Sequence"), (b"", "EntryID")):
+        with pytest.raises(RuntimeError, match=msg):
+            api.Proteins.from_tsv(bad)
+        with pytest.raises(ValueError, match=msg):
+            _makedb_ref().run_tsv(bad)
+
+
+def test_random_fasta_against_the_restatement(klib, oracle):
+    rng = np.random.default_rng(11)
+    aa = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWYacdefgXBZ.*", dtype=np.uint8)
+    out = []
+    for i in range(600):
+        name = [b"kinase", b"hypothetical protein, partial", b"", b"transporter, partial cds", b"x y z"][int(rng.integers(0, 5))]
+        out.append(b">E%d%s%s" % (i, b" " if name or i % 3 else b"", name))
+        n = int(rng.integers(0, 160))
+        seq = bytes(aa[rng.integers(0, len(aa), n)])
+        w = int(rng.integers(20, 70))
+        out += [seq[j:j + w] for j in range(0, n, w)]
+    text = b"\n".join(out) + b"\n"
+    ref = _makedb_ref().run_fasta(text)
+    p = api.Proteins.from_fasta(text)
+    buf, offs = p.packed
+    assert p.ids.tolist() == [r[0] for r in ref] and len(ref) > 250
+    assert [bytes(buf[int(offs[j]):int(offs[j + 1])]) for j in range(len(p))] == [r[2] for r in ref]
+    oix = _pairs_of(ref, oracle)
+    whole = p.image()
+    _image_pairs(whole, oix)
+    # the same proteins built as 4 shards hold the same postings between them
+    keys = np.unique((oix.pairs() >> np.uint64(32)).astype(np.uint32))
+    shards = [p.image(shard=s, n_shards=4) for s in range(4)]
+    assert sum(s.stats()["n_keys"] for s in shards) == len(keys)
+    for k in keys[:: max(1, len(keys) // 500)]:
+        assert sum(len(s.get(int(k))) for s in shards) == len(whole.get(int(k)))
+    last = {r[0]: r for r in ref}
+    ents = p.fetch_hits(sorted(last))
+    for e, i in zip(ents, sorted(last)):
+        assert (e["EntryId"], e["Sequence"], e["Features"][b"ProteinName"]) == (last[i][1], last[i][2], last[i][3][b"ProteinName"])
+
+
+def test_protein_table_file_round_trip_and_validation(klib, tmp_path):
+    p = api.Proteins.from_tsv(TSV)
+    path = tmp_path / "proteins.kpt"
+    p.save(path)
+    q = api.Proteins.load(path)
+    assert q.ids.tolist() == p.ids.tolist() and q.feature_names == p.feature_names and q.stats() == p.stats()
+    assert q.fetch_hits([0, 1, 2, 3, 4]) == p.fetch_hits([0, 1, 2, 3, 4])
+    raw = path.read_bytes()
+    for bad in (raw[:-3], raw + b"\0", raw[:40], b"\0" * 64):
+        path.write_bytes(bad)
+        with pytest.raises(RuntimeError):
+            api.Proteins.load(path)
+    hdr = bytearray(raw)
+    hdr[8:16] = (2 ** 40).to_bytes(8, "little")          # a protein count the file cannot hold
+    path.write_bytes(bytes(hdr))
+    with pytest.raises(RuntimeError):
+        api.Proteins.load(path)
