@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -72,6 +73,19 @@ void sort_u64(uint64_t *a, size_t n)
     free(tmp);
 }
 
+// KAAMER_BUILD_TRACE=1: phase times of a build on stderr
+struct Trace {
+    bool on = getenv("KAAMER_BUILD_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char *what, uint64_t n)
+    {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[kaamer build] %-22s %8.2f s  (%llu)\n", what, std::chrono::duration<double>(now - t).count(), (unsigned long long)n);
+        t = now;
+    }
+};
+
 uint64_t hash_list(const uint32_t *ids, uint32_t n)
 {
     uint64_t h = 0x9E3779B97F4A7C15ull ^ n;
@@ -103,8 +117,11 @@ static int build_from_sorted_input(uint64_t *pairs64, uint64_t n, uint32_t shard
                                    double load, kaamer_image **out)
 {
     if (!(load > 0.05 && load <= 0.95)) load = 0.5;
+    Trace tr;
     sort_u64(pairs64, n);
+    tr.lap("sort pairs", n);
     n = (uint64_t)(std::unique(pairs64, pairs64 + n) - pairs64);
+    tr.lap("unique", n);
 
     // distinct keys
     uint64_t n_keys = 0;
@@ -222,6 +239,7 @@ static int build_from_sorted_input(uint64_t *pairs64, uint64_t n, uint32_t shard
         if (!home) n_displaced++;
         i = j;
     }
+    tr.lap("lists + placement", n_keys);
     img->hdr.arena_words = words;
     img->hdr.n_inline = n_inline;
     img->hdr.n_lists = n_lists;

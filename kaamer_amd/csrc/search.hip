@@ -99,7 +99,7 @@ static_assert(sizeof(kaamer_counters) == CTR_N * 8, "counter layout");
 enum { LIST_S = 0, LIST_L, LIST_SO, LIST_G, N_LISTS };
 // small per-batch device state after the list counters (all zeroed by the finalize step)
 enum { SLOT_QUEUE_HEAD = N_LISTS, SLOT_STATUS = N_LISTS + 1, SLOT_GROUP_QUEUE = N_LISTS + 2, SLOT_GROUP_QUEUE_POS = N_LISTS + 3,
-       SLOT_N_LONG = N_LISTS + 4, SLOT_TILES_DONE = N_LISTS + 5, N_SMALL_SLOTS = N_LISTS + 6 };
+       SLOT_N_LONG = N_LISTS + 4, SLOT_TILES_DONE = N_LISTS + 5, SLOT_TR_TICKET = N_LISTS + 6, N_SMALL_SLOTS = N_LISTS + 7 };
 // one entry: everything a tier needs to start on a query, in one 16-byte load
 struct alignas(16) WorkItem {
     uint32_t q;
@@ -170,7 +170,11 @@ struct ProbeParams {
 #define P_RING 128u            /* deferred lookups per wave (a power of two): fewer than 64 waiting + the 64 of a window */
 #define KH_NO_KEY 0xFFFFFFFDu  /* "no lookup for this position": equals no slot key (valid keys <= 0xE773B9D4, 0xFFFFFFFF = empty) */
 
-__global__ __launch_bounds__(64 * P_WAVES) void probe_kernel(ProbeParams p)
+// SKIP_IDLE: lanes without a lookup issue no bucket load.  A nucleotide batch has one position in six that starts no
+// k-mer (the gaps between ORFs); a load is a request whatever it hits, and the probe runs at the request rate of the
+// memory system, so there the exec-masked loads win although their waits are coarser.  Protein batches (1.7 % idle
+// positions, a few windows per wave) keep the unconditional, exactly counted loads.
+template <bool SKIP_IDLE> __global__ __launch_bounds__(64 * P_WAVES) void probe_kernel(ProbeParams p)
 {
     __shared__ uint8_t s_lut[256];
     __shared__ uint8_t s_stage[P_WAVES][80];
@@ -263,8 +267,16 @@ __global__ __launch_bounds__(64 * P_WAVES) void probe_kernel(ProbeParams p)
             }
             typedef uint32_t v4u __attribute__((ext_vector_type(4)));
             const v4u *srcp = reinterpret_cast<const v4u *>(p.table) + (uint64_t)bucket * 4 + (lane & 3u);
-            const v4u t = p.nontemporal ? __builtin_nontemporal_load(srcp) : *srcp;
-            ld[j] = make_uint4(t.x, t.y, t.z, t.w);
+            if (SKIP_IDLE) {
+                ld[j] = make_uint4(KH_EMPTY_KEY, 0u, KH_EMPTY_KEY, 0u);
+                if (rk[j] != KH_NO_KEY) {
+                    const v4u t = *srcp;
+                    ld[j] = make_uint4(t.x, t.y, t.z, t.w);
+                }
+            } else {
+                const v4u t = p.nontemporal ? __builtin_nontemporal_load(srcp) : *srcp;
+                ld[j] = make_uint4(t.x, t.y, t.z, t.w);
+            }
         }
         // ---- consume: lane 4g+j ends up owning the lookup of lane 16j+g
         uint32_t okey = KH_NO_KEY, oval = 0, oempty = 1u, ostep = 0;
@@ -1032,6 +1044,8 @@ struct kaamer_workspace {
     kaamer_query_meta *d_rep_q;
     uint8_t *d_rep_aa;
     uint32_t lay_epoch;
+    unsigned long long *d_tr_chain;     // translate_reads_kernel: three words per 64-sequence chunk, tagged with tr_epoch
+    uint32_t tr_epoch;
     uint32_t *d_list_counts;            // [N_LISTS] + queue head + status (zeroed by finalize)
     uint32_t *d_status_out;             // status of the last finished batch
     bool clean;                         // per-batch device state is known to be zeroed
@@ -1141,7 +1155,7 @@ void kaamer_workspace_free(kaamer_workspace *ws)
                      ws->d_tmp_meta, ws->d_orf_aa, ws->d_starts_alt, ws->d_q_cnt, ws->d_csr_off, ws->d_c_pid, ws->d_c_km, ws->d_c_fp,
                      ws->d_pool_cursor, ws->d_lists, ws->d_list_counts, ws->d_status_out, ws->d_qinfo, ws->d_slots,
                      ws->d_slot_off, ws->d_group_first, ws->d_n_groups, ws->d_pos_words, ws->d_pos_base, ws->d_pos_off, ws->d_pos_bits, ws->d_g_keys,
-                     ws->d_g_cnt, ws->d_g_min, ws->d_counter_replicas, ws->d_counters, ws->d_bsum, ws->d_chain, ws->d_sched, ws->d_n_sched, ws->d_group_start, ws->d_lay_total, ws->d_top_cnt, ws->d_top_pid, ws->d_top_km, ws->d_top_fp, ws->d_top_trim, ws->d_top_start, ws->d_top_size, ws->d_rep_flag, ws->d_rep_aalen, ws->d_rep_query, ws->d_rep_pid, ws->d_rep_km, ws->d_rep_fp, ws->d_rep_trim, ws->d_rep_rank, ws->d_rep_eoff, ws->d_rep_aoff, ws->d_rep_off, ws->d_rep_q, ws->d_rep_aa, ws->d_hit_off,
+                     ws->d_g_cnt, ws->d_g_min, ws->d_counter_replicas, ws->d_counters, ws->d_bsum, ws->d_chain, ws->d_tr_chain, ws->d_sched, ws->d_n_sched, ws->d_group_start, ws->d_lay_total, ws->d_top_cnt, ws->d_top_pid, ws->d_top_km, ws->d_top_fp, ws->d_top_trim, ws->d_top_start, ws->d_top_size, ws->d_rep_flag, ws->d_rep_aalen, ws->d_rep_query, ws->d_rep_pid, ws->d_rep_km, ws->d_rep_fp, ws->d_rep_trim, ws->d_rep_rank, ws->d_rep_eoff, ws->d_rep_aoff, ws->d_rep_off, ws->d_rep_q, ws->d_rep_aa, ws->d_hit_off,
                      ws->d_hit_pid, ws->d_hit_km, ws->d_hit_fp, ws->d_x_dst_off, ws->d_x_src_off, ws->d_x_nq_owned, ws->d_x_pid, ws->d_x_km, ws->d_x_fp, ws->d_x_ent_off };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (ws->ev) {
@@ -1192,7 +1206,9 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     hipError_t oe = ws->firstpos
         ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&grp_per_cu, count_group_kernel<true, 0>, 64 * GRP_WAVES, 0)
         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&grp_per_cu, count_group_kernel<false, 0>, 64 * GRP_WAVES, 0);
-    if (oe == hipSuccess) oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&p_per_cu, probe_kernel, 64 * P_WAVES, 0);
+    if (oe == hipSuccess)
+        oe = ws->nucleotide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&p_per_cu, probe_kernel<true>, 64 * P_WAVES, 0)
+                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&p_per_cu, probe_kernel<false>, 64 * P_WAVES, 0);
     if (oe != hipSuccess) { delete ws; return kaamer_fail(KAAMER_E_HIP, "occupancy query: %s", hipGetErrorString(oe)); }
     hipDeviceProp_t prop;
     hipError_t pe = hipGetDeviceProperties(&prop, ix->device);
@@ -1239,6 +1255,9 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
         if (!rc) rc = dev_alloc(&ws->d_poff3, 3 * ((size_t)ws->max_piece_items + 1));
         if (!rc) rc = dev_alloc(&ws->d_n_piece_items, 1);
         if (!rc) rc = dev_alloc(&ws->d_tmp_meta, ws->q_cap);
+        const size_t tcw = 3 * ((size_t)ws->max_seqs / 64 + 2);
+        if (!rc) rc = dev_alloc(&ws->d_tr_chain, tcw);
+        if (!rc && hipMemset(ws->d_tr_chain, 0, tcw * sizeof(unsigned long long)) != hipSuccess) rc = kaamer_fail(KAAMER_E_HIP, "memset");
         if (!rc) rc = dev_alloc(&ws->d_orf_aa, (size_t)ws->aa_cap + 64);
         if (!rc) rc = dev_alloc(&ws->d_starts_alt, (size_t)ws->sa_cap + 64);
     }
@@ -1431,27 +1450,24 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         const uint64_t piece_bound = 6ull * (seq_bytes / 3 / TP_PIECE + n_long_bound + 1);
         if ((uint64_t)tgrid * 4 > piece_bound) tgrid = (int)((piece_bound + 3) / 4);
         if (tgrid < 1) tgrid = 1;
-        hipLaunchKernelGGL(translate_short_kernel<false>, dim3(sgrid), dim3(64 * TS_WAVES), 0, s, tp);
+        tp.ticket = ws->d_list_counts + SLOT_TR_TICKET;
+        tp.chain = ws->d_tr_chain;
+        ws->tr_epoch = (ws->tr_epoch + 1u) & 0xFFFFFFu;
+        if (ws->tr_epoch == 0) ws->tr_epoch = 1;
+        tp.epoch = ws->tr_epoch;
+        tp.out_meta = ws->d_q; tp.d_nq = ws->d_nq; tp.d_n_pos = ws->d_n_pos;
+        tp.w_off_orf = ws->d_off3; tp.w_off_aa = ws->d_off3 + (cap6 + 1); tp.w_off_sa = ws->d_off3 + 2 * (cap6 + 1);
+        // long sequences first (listed, cut in pieces, counted: a wave per piece) -- a reads-only batch falls through
+        // these launches; then everything of the reads and the output offsets of both kinds in one kernel
+        hipLaunchKernelGGL(list_long_kernel, dim3((unsigned)(((uint64_t)n_seqs + 255) / 256 + (n_seqs ? 0 : 1))), dim3(256), 0, s, tp);
         scan_u32(ws->d_long_np, tp.n_long, n_long_bound, ws->d_piece_base);
         hipLaunchKernelGGL(translate_kernel<false>, dim3(tgrid), dim3(256), 0, s, tp);
         for (int a = 0; a < 3; a++) scan_u32(ws->d_pcnt3 + a * mpi, ws->d_n_piece_items, piece_bound, ws->d_poff3 + a * (mpi + 1));
         hipLaunchKernelGGL(long_totals_kernel, dim3((unsigned)((n_long_bound * 6 + 255) / 256)), dim3(256), 0, s, tp);
-        const uint32_t nsb6 = (uint32_t)((n6 + 1 + SCAN_TILE - 1) / SCAN_TILE);
-        for (int a = 0; a < 3; a++) {
-            const uint32_t *cnt = ws->d_cnt3 + a * cap6;
-            uint64_t *off = ws->d_off3 + a * (cap6 + 1);
-            if (n6 <= 8 * (size_t)SCAN_TILE) {
-                hipLaunchKernelGGL(scan_single_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, cnt, ws->d_n6, off);
-            } else {
-                hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nsb6), dim3(SCAN_BLOCK), 0, s, cnt, ws->d_n6, ws->d_bsum);
-                hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, ws->d_bsum, nsb6);
-                hipLaunchKernelGGL(scan_apply_kernel, dim3(nsb6), dim3(SCAN_BLOCK), 0, s, cnt, ws->d_n6, ws->d_bsum, off);
-            }
-        }
+        hipLaunchKernelGGL(translate_reads_kernel, dim3(sgrid), dim3(64 * TS_WAVES), 0, s, tp);
         hipLaunchKernelGGL(translate_kernel<true>, dim3(tgrid), dim3(256), 0, s, tp);
-        hipLaunchKernelGGL(translate_short_kernel<true>, dim3(sgrid), dim3(64 * TS_WAVES), 0, s, tp);
-        hipLaunchKernelGGL(orf_order_kernel, dim3(ws->n_cu * 4), dim3(256), 0, s, ws->d_tmp_meta, tp.off_orf, n_seqs, ws->d_q,
-                           ws->d_nq, ws->d_n_pos, tp.off_aa, (uint64_t)ws->q_cap, status);
+        hipLaunchKernelGGL(orf_order_long_kernel, dim3((unsigned)(n_long_bound < 1024 ? (n_long_bound ? n_long_bound : 1) : 1024)), dim3(256), 0, s,
+                           ws->d_tmp_meta, tp.off_orf, ws->d_long_seq, tp.n_long, ws->d_q, ws->d_nq);
         hipLaunchKernelGGL(prep_orf_kernel, dim3(ws->n_cu * 4), dim3(pb), 0, s, ws->d_q, ws->d_nq, ws->d_valid, ws->d_n_pos,
                            ws->d_qinfo, ws->d_slots, ws->d_hit_off, ws->d_q_cnt);
         residues = ws->d_orf_aa;
@@ -1478,7 +1494,8 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     if (p_blocks > (uint64_t)ws->p_grid) p_blocks = ws->p_grid;
     if (p_blocks < 1) p_blocks = 1;
     if (timed) HIPCHK(hipEventRecord(ev[1], s));
-    hipLaunchKernelGGL(probe_kernel, dim3((unsigned)p_blocks), dim3(64 * P_WAVES), 0, s, pp);
+    if (ws->nucleotide) hipLaunchKernelGGL(probe_kernel<true>, dim3((unsigned)p_blocks), dim3(64 * P_WAVES), 0, s, pp);
+    else hipLaunchKernelGGL(probe_kernel<false>, dim3((unsigned)p_blocks), dim3(64 * P_WAVES), 0, s, pp);
     if (timed) HIPCHK(hipEventRecord(ev[2], s));
     // ---- kernel C: counting
     CountParams p;
