@@ -55,10 +55,25 @@ def log(*a):
 
 
 def host_cores():
+    """CPUs this process may actually use: the affinity mask, cut down to the cgroup's CPU quota when there is one
+    (a GPU box shows all of the host's CPUs in the mask but schedules the container on a share of them)."""
     try:
-        return len(os.sched_getaffinity(0))
+        n = len(os.sched_getaffinity(0))
     except Exception:
-        return os.cpu_count() or 1
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            f = open(path).read().split()
+            if path.endswith("cpu.max"):
+                quota, period = f[0], float(f[1])
+            else:
+                quota, period = f[0], float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota not in ("max", "-1"):
+                n = max(1, min(n, int(float(quota) / period + 0.5)))
+            break
+        except Exception:
+            continue
+    return n
 
 
 def cpu_baseline(oix, queries, seconds=12.0, threads=None, kind="protein"):
@@ -118,6 +133,10 @@ def main():
     ap.add_argument("--distinct-batches", type=int, default=8,
                     help="different pre-generated batches the steps rotate over (their bucket footprint exceeds the Infinity Cache)")
     ap.add_argument("--load-factor", type=float, default=0.5)
+    ap.add_argument("--g-tier-slots", type=int, default=0,
+                    help="workspace bound: slots of the HBM counting tables of queries that overflow their LDS table "
+                         "(default: the library's 32 M; 1 G for --db zipf, where most queries overflow)")
+    ap.add_argument("--max-hits", type=int, default=0, help="workspace bound: hit entries per batch (default: sized for the workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--check", type=int, default=50, help="queries checked against the oracle after timing")
@@ -154,7 +173,10 @@ def main():
     if args.queries <= 0:
         args.queries = 1000000 if nucl else 10000
     if args.batches_per_step <= 0:
-        args.batches_per_step = 3 if nucl else 200
+        args.batches_per_step = 3 if nucl else (20 if args.db == "zipf" else 200)
+    if args.db == "zipf":
+        args.g_tier_slots = args.g_tier_slots or (1 << 30)
+        args.max_hits = args.max_hits or (1 << 28)
     _tame_malloc()
     import numpy as np
     import torch
@@ -204,7 +226,8 @@ def main():
     d_bufs = [torch.from_numpy(q[0]).cuda() for q in batches]
     d_offs = [torch.from_numpy(q[1].view(np.int64)).cuda() for q in batches]
     max_bytes = max(len(q[0]) for q in batches)
-    ws_kw = dict(seq_type=seq_type, max_hits=(64 << 20) if nucl else 0, compact=bool(args.compact))
+    ws_kw = dict(seq_type=seq_type, max_hits=args.max_hits or ((64 << 20) if nucl else 0), g_tier_slots=args.g_tier_slots,
+                 compact=bool(args.compact))
     stream = torch.cuda.current_stream().cuda_stream
 
     if sharded_mode:
@@ -300,8 +323,9 @@ def main():
     #   count kernels: 4 B per position (val read back) + 4 B per arena word that must be read (list header + ids)
     #                  + 28 B per query read (descriptor 16 + table offset 8 + hit count 4) + 8 B per query written
     #                  + 8 or 12 B per emitted hit (pid, Kmatch[, first position])
-    #   rest of the batch: prep (8 B offsets + 40 B meta + 24 B descriptor/offset per query), translation for nucleotide
-    #                  input (1 B per nucleotide read twice: COUNT + WRITE; ORF residues and 40 B of meta per ORF)
+    #   rest of the batch: prep (8 B offsets + 40 B meta + 24 B descriptor/offset per query); nucleotide input: translation
+    #                  (1 B per nucleotide + 8 B of offsets per read in; 1 B per ORF residue + 40 B of meta per ORF out) and
+    #                  the ORF prep (40 B meta in, 32 B descriptor / table size / hit offset / count out per ORF)
     c = avg
     hit_b = 12 if (nucl or sharded_mode) else 8
     n_pos = c["n_in"] if nucl else float(np.mean([len(q[0]) for q in batches]))  # positions kernel P walks
@@ -309,7 +333,7 @@ def main():
     count_bytes = 4 * n_pos + 4 * (c["n_lists"] + c["n_list_ids"]) + 36 * c["n_queries"] + hit_b * c["n_hits"]
     if nucl:
         nt = float(np.mean([len(q[0]) for q in batches]))
-        rest_bytes = 2 * nt + 48 * args.queries + c["n_in"] + 64 * c["n_queries"]
+        rest_bytes = nt + 8 * args.queries + c["n_in"] + 112 * c["n_queries"]
     else:
         rest_bytes = 9 * args.queries + 72 * c["n_queries"]
     probe_s = tm["probe_ms"] / n_calls / 1e3
@@ -363,7 +387,7 @@ def main():
         "config": {"workload": cfg_workload + ("Swiss-Prot-sized synthetic DB" if args.db == "sp" else "Zipf-motif synthetic DB") +
                                " (%d proteins, %d residues, %d distinct 7-mers, longest postings list %d) resident in HBM"
                                % (args.db_proteins, int(db[1][-1]), st["n_keys"], st["max_list"]),
-                   "batches_per_step": args.batches_per_step, "distinct_batches": n_distinct,
+                   "queries_per_batch": args.queries, "batches_per_step": args.batches_per_step, "distinct_batches": n_distinct,
                    "ms_per_batch": step_s * 1e3,
                    "parallelism": ("hash-prefix shards x%d, one exchange of partial hit lists per batch" % world) if sharded_mode
                                   else ("replicas x%d (no collective)" % world if world > 1 else "single GPU"),

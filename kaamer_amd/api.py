@@ -225,38 +225,54 @@ class TopResult:
 
 
 class BatchResult:
-    """Host view of one kaamer_batch_out (copied out, the C object is freed)."""
+    """Host view of one kaamer_batch_out: the arrays are views of the C object's buffers (no copies), which
+    this object owns and frees with itself."""
 
     def __init__(self, out):
+        self._out = out
         o = out.contents
         n = o.n_queries
         self.n_queries = n
-        meta = np.ctypeslib.as_array(C.cast(o.q, C.POINTER(C.c_uint8)), shape=(n * C.sizeof(abi.QueryMeta),)).copy() \
-            if n else np.zeros(0, np.uint8)
+        view = np.ctypeslib.as_array
+        meta = view(C.cast(o.q, C.POINTER(C.c_uint8)), shape=(n * C.sizeof(abi.QueryMeta),)) if n else np.zeros(0, np.uint8)
         self.meta = meta.view(np.dtype([("src_seq", "<u4"), ("size_in_kmer", "<i4"), ("start_position", "<i4"),
                                         ("end_position", "<i4"), ("plus_strand", "<i4"), ("aa_len", "<u4"),
                                         ("aa_off", "<u8"), ("sa_off", "<u4"), ("sa_len", "<u4")]))
-        self.hit_off = np.ctypeslib.as_array(o.hit_off, shape=(n + 1,)).copy()
-        self.hit_cnt = np.ctypeslib.as_array(o.hit_cnt, shape=(n,)).copy() if n else np.zeros(0, np.uint32)
+        self.hit_off = view(o.hit_off, shape=(n + 1,))
+        self.hit_cnt = view(o.hit_cnt, shape=(n,)) if n else np.zeros(0, np.uint32)
         nh = int(self.hit_off[n])
         z = np.zeros(0, np.uint32)
-        self.hit_pid = np.ctypeslib.as_array(o.hit_pid, shape=(nh,)).copy() if nh else z
-        self.hit_kmatch = np.ctypeslib.as_array(o.hit_kmatch, shape=(nh,)).copy() if nh else z
-        self.hit_first_pos = np.ctypeslib.as_array(o.hit_first_pos, shape=(nh,)).copy() if nh else z
+        self.hit_pid = view(o.hit_pid, shape=(nh,)) if nh else z
+        self.hit_kmatch = view(o.hit_kmatch, shape=(nh,)) if nh else z
+        self.hit_first_pos = view(o.hit_first_pos, shape=(nh,)) if nh else z
         self.counters = o.counters.as_dict()
         self.pos_off = self.pos_bits = None
         if bool(o.pos_off) and bool(o.pos_bits):
-            self.pos_off = np.ctypeslib.as_array(o.pos_off, shape=(nh,)).copy() if nh else np.zeros(0, np.uint64)
+            self.pos_off = view(o.pos_off, shape=(nh,)) if nh else np.zeros(0, np.uint64)
             nw = 0
-            for q in range(n):  # words in use = end of the last bitmap
-                if self.hit_cnt[q]:
-                    last = int(self.hit_off[q]) + int(self.hit_cnt[q]) - 1
-                    nw = max(nw, int(self.pos_off[last]) + (int(self.meta["size_in_kmer"][q]) + 63) // 64)
-            self.pos_bits = np.ctypeslib.as_array(o.pos_bits, shape=(nw,)).copy() if nw else np.zeros(0, np.uint64)
+            if nh:  # words in use = end of the last bitmap
+                has = self.hit_cnt > 0
+                last = (self.hit_off[:n][has] + self.hit_cnt[has].astype(np.uint64) - np.uint64(1)).astype(np.int64)
+                words = (self.meta["size_in_kmer"][has].astype(np.int64) + 63) // 64
+                nw = int((self.pos_off[last].astype(np.int64) + words).max())
+            self.pos_bits = view(o.pos_bits, shape=(nw,)) if nw else np.zeros(0, np.uint64)
         aa_len = int((self.meta["aa_off"] + self.meta["aa_len"]).max()) if n and bool(o.orf_aa) else 0
-        self.orf_aa = np.ctypeslib.as_array(o.orf_aa, shape=(aa_len,)).copy() if aa_len else np.zeros(0, np.uint8)
+        self.orf_aa = view(o.orf_aa, shape=(aa_len,)) if aa_len else np.zeros(0, np.uint8)
         sa_len = int((self.meta["sa_off"] + self.meta["sa_len"]).max()) if n and bool(o.starts_alt) else 0
-        self.starts_alt = np.ctypeslib.as_array(o.starts_alt, shape=(sa_len,)).copy() if sa_len else np.zeros(0, np.int32)
+        self.starts_alt = view(o.starts_alt, shape=(sa_len,)) if sa_len else np.zeros(0, np.int32)
+
+    def close(self):
+        if self._out is not None:
+            for k in ("meta", "hit_off", "hit_cnt", "hit_pid", "hit_kmatch", "hit_first_pos", "pos_off", "pos_bits", "orf_aa", "starts_alt"):
+                setattr(self, k, None)  # the views die with the buffers
+            abi.lib().kaamer_batch_free(self._out)
+            self._out = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def span(self, q):
         """[first, last+1) of query q's hits in the hit arrays"""
@@ -318,10 +334,7 @@ class Index:
                          int(want_positions))
         out = C.POINTER(abi.BatchOut)()
         abi.check(abi.lib().kaamer_search_batch(self._h, C.byref(bi), C.byref(out)))
-        try:
-            return BatchResult(out)
-        finally:
-            abi.lib().kaamer_batch_free(out)
+        return BatchResult(out)
 
     def search_top(self, seqs=None, packed=None, seq_type=abi.PROTEIN, min_k_ratio=0.05, min_k_match=10, max_results=10):
         """Host-buffer form that returns the reported hits only (kaamer_search_batch_top):

@@ -213,12 +213,13 @@ def make_reads_mix(db, n_reads, seed=SEED + 3, db_frac=0.9, subst=0.01, n_rate=0
     return np.ascontiguousarray(out), roffs
 
 
-def make_db_zipf(n_proteins, seed=SEED + 7, n_motifs=100000, zipf_a=0.8, per_residues=60):
+def make_db_zipf(n_proteins, seed=SEED + 7, n_motifs=300000, zipf_a=0.7, per_residues=120):
     """A DB of the size and length distribution of DB-SP whose shared content follows a power law, like the
     domain families of a real protein database: proteins are random background with motifs (15..40 residues)
     pasted in, one per `per_residues` residues, the motif drawn with P(rank r) ~ r^-zipf_a from a library of
-    `n_motifs`.  The most frequent motifs occur in 1e4..1e5 proteins, so their 7-mers have postings lists of
-    that length (the stress case for the postings expansion and the counting tables)."""
+    `n_motifs`.  The most frequent motifs occur in ~1e4 proteins, so their 7-mers have postings lists of that
+    length and a query expands ~25 times the postings of a DB-SP query, most of them past the LDS counting
+    tables (the stress case for the postings expansion and the HBM counting tier)."""
     rng = np.random.default_rng(seed)
     lens = _lengths(rng, n_proteins)
     offs = _offsets(lens)
