@@ -449,6 +449,11 @@ const uint64_t *kaamer_reads_offsets(const kaamer_reads *r);       /* count + 1 
 const int32_t *kaamer_reads_size_in_kmer(const kaamer_reads *r);
 const char *kaamer_reads_names(const kaamer_reads *r);
 const uint64_t *kaamer_reads_name_offsets(const kaamer_reads *r);  /* count + 1 */
+/* Location.PlusStrand as the reference's reader leaves it: 1 for the first record, 0 (Go's zero value) for every
+ * following one (search.go:297,399 rebuild the Query without a Location); protein results report it unchanged.
+ * Not reproduced: bufio.Scanner's 1 MiB line limit (search.go:273-274: a longer line silently ends the
+ * reference's scan) -- lines of any length are read. */
+const int32_t *kaamer_reads_plus_strand(const kaamer_reads *r);
 void kaamer_reads_free(kaamer_reads *r);
 
 #ifdef __cplusplus

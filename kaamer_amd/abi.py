@@ -173,6 +173,7 @@ SYMBOLS = {
     "kaamer_reads_size_in_kmer": (C.POINTER(C.c_int32), [C.c_void_p]),
     "kaamer_reads_names": (C.POINTER(C.c_char), [C.c_void_p]),
     "kaamer_reads_name_offsets": (C.POINTER(C.c_uint64), [C.c_void_p]),
+    "kaamer_reads_plus_strand": (C.POINTER(C.c_int32), [C.c_void_p]),
     "kaamer_reads_free": (None, [C.c_void_p]),
 }
 

@@ -446,7 +446,7 @@ class Workspace:
 
 
 def parse_reads(text, fmt="fasta"):
-    """GetQueriesFasta / GetQueriesFastq on a text buffer -> list of dict(seq, name, size)"""
+    """GetQueriesFasta / GetQueriesFastq on a text buffer -> list of dict(seq, name, size, plus)"""
     data = text.encode("latin-1") if isinstance(text, str) else bytes(text)
     h = C.c_void_p()
     f = abi.lib().kaamer_parse_fasta if fmt == "fasta" else abi.lib().kaamer_parse_fastq
@@ -459,7 +459,9 @@ def parse_reads(text, fmt="fasta"):
         seqs = bytes(np.ctypeslib.as_array(L.kaamer_reads_seqs(h), shape=(int(offs[n]),))) if offs[n] else b""
         names = bytes(np.ctypeslib.as_array(C.cast(L.kaamer_reads_names(h), C.POINTER(C.c_uint8)), shape=(int(noff[n]),))) if noff[n] else b""
         size = np.ctypeslib.as_array(L.kaamer_reads_size_in_kmer(h), shape=(n,)).copy() if n else np.zeros(0, np.int32)
+        plus = np.ctypeslib.as_array(L.kaamer_reads_plus_strand(h), shape=(n,)).copy() if n else np.zeros(0, np.int32)
         return [dict(seq=seqs[int(offs[i]):int(offs[i + 1])].decode("latin-1"),
-                     name=names[int(noff[i]):int(noff[i + 1])].decode("latin-1"), size=int(size[i])) for i in range(n)]
+                     name=names[int(noff[i]):int(noff[i + 1])].decode("latin-1"), size=int(size[i]), plus=bool(plus[i]))
+                for i in range(n)]
     finally:
         abi.lib().kaamer_reads_free(h)

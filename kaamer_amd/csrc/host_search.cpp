@@ -21,6 +21,7 @@ struct kaamer_reads {
     std::vector<int32_t> size_in_kmer;
     std::vector<char> names;
     std::vector<uint64_t> name_off;  // n + 1
+    std::vector<int32_t> plus_strand;  // Location.PlusStrand as the reference's reader leaves it
 };
 
 namespace {
@@ -51,6 +52,10 @@ void push_record(kaamer_reads *r, const std::string &seq, const std::string &nam
     r->size_in_kmer.push_back(size);
     r->names.insert(r->names.end(), name.begin(), name.end());
     r->name_off.push_back(r->names.size());
+    // Both readers build the first Query with Location{PlusStrand: true} and every following one as
+    // Query{Sequence: "", ...} (search.go:297,399): Location is then Go's zero value, PlusStrand false.  Protein results
+    // report that field as it is (search_protein.go never sets it); for nucleotide input GetORFs overwrites it.
+    r->plus_strand.push_back(r->plus_strand.empty() ? 1 : 0);
 }
 
 }  // namespace
@@ -130,6 +135,7 @@ const uint64_t *kaamer_reads_offsets(const kaamer_reads *r) { return r ? r->offs
 const int32_t *kaamer_reads_size_in_kmer(const kaamer_reads *r) { return r ? r->size_in_kmer.data() : nullptr; }
 const char *kaamer_reads_names(const kaamer_reads *r) { return r ? r->names.data() : nullptr; }
 const uint64_t *kaamer_reads_name_offsets(const kaamer_reads *r) { return r ? r->name_off.data() : nullptr; }
+const int32_t *kaamer_reads_plus_strand(const kaamer_reads *r) { return r ? r->plus_strand.data() : nullptr; }
 void kaamer_reads_free(kaamer_reads *r) { delete r; }
 
 // SetBestStartCodon, dna.go:198-272.  hits must be in sortMapByValue order (Kmatch

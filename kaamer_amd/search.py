@@ -54,7 +54,7 @@ def ProteinSearch(index, fasta_text, options=None):
             q = queries[int(top.rep_query[r])]
             a, b = int(top.top_off[r]), int(top.top_off[r + 1])
             out.append({"Query": {"Sequence": q["seq"], "Name": q["name"], "SizeInKmer": q["size"], "Type": PROTEIN_QUERY,
-                                  "Location": {"StartPosition": 1, "EndPosition": len(q["seq"]), "PlusStrand": True,
+                                  "Location": {"StartPosition": 1, "EndPosition": len(q["seq"]), "PlusStrand": q["plus"],
                                                "StartsAlternative": []}, "Contig": ""},
                         "SearchResults": {"Hits": [{"Key": int(p), "Kmatch": int(k)}
                                                    for p, k in zip(top.top_pid[a:b], top.top_kmatch[a:b])]}})
@@ -69,7 +69,7 @@ def ProteinSearch(index, fasta_text, options=None):
         if keep == 0:  # search_protein.go:108
             continue
         qr = {"Query": {"Sequence": q["seq"], "Name": q["name"], "SizeInKmer": q["size"], "Type": PROTEIN_QUERY,
-                        "Location": {"StartPosition": 1, "EndPosition": len(q["seq"]), "PlusStrand": True,
+                        "Location": {"StartPosition": 1, "EndPosition": len(q["seq"]), "PlusStrand": q["plus"],
                                      "StartsAlternative": []}, "Contig": ""},
               "SearchResults": {"Hits": [{"Key": int(p), "Kmatch": int(k)} for p, k in zip(pid[:keep], km[:keep])]}}
         if o.ExtractPositions:

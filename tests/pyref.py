@@ -251,7 +251,9 @@ def get_queries_fasta(text, is_protein=True):
                 size = len(seq) - KMER_SIZE + 1
                 if seq[-1:] == "*":
                     size -= 1
-                out.append(dict(seq=seq.upper(), name=name, size=size, end=len(seq)))
+                # the first Query carries Location{PlusStrand: true} (search.go:224-229); the reader then rebuilds
+                # query = Query{Sequence: "", ...} (search.go:297): every later record has Go's zero Location
+                out.append(dict(seq=seq.upper(), name=name, size=size, end=len(seq), plus=len(out) == 0))
                 seq = ""
             name = l[1:]
             have = True
@@ -261,7 +263,7 @@ def get_queries_fasta(text, is_protein=True):
         size = len(seq) - KMER_SIZE + 1
         if seq[-1:] == "*":
             size -= 1
-        out.append(dict(seq=seq, name=name, size=size, end=len(seq)))  # NOT upper-cased (search.go:313-320)
+        out.append(dict(seq=seq, name=name, size=size, end=len(seq), plus=len(out) == 0))  # NOT upper-cased (search.go:313-320)
     return out
 
 

@@ -168,6 +168,8 @@ def test_readers_match_reference_restatement(klib):
     assert [(g["seq"], g["name"], g["size"]) for g in got] == [(e["seq"], e["name"], e["size"]) for e in exp]
     assert got[0]["seq"] == "MKVLAAGTACDEFGHIKL" and got[-1]["seq"] == "mkvlaagtacdefghik*"   # last record keeps its case
     assert got[1]["size"] == len(got[1]["seq"]) - 7
+    # Location.PlusStrand as the reader leaves it: true on the first record only (search.go:224-229 vs :297)
+    assert [g["plus"] for g in got] == [e["plus"] for e in exp] == [True, False, False]
     for _ in range(50):
         recs = []
         for i in range(rng.randint(0, 6)):
