@@ -153,8 +153,11 @@ def main():
                     help="1: also time the host-buffer calls once (PCIe-inclusive, informational, never `value`)")
     ap.add_argument("--exchange-entries", type=int, default=0,
                     help="sharded mode: partial hit entries one exchange block holds (default: sized for the workload)")
-    ap.add_argument("--inflight", type=int, default=1,
-                    help="batches in flight: batch i runs on workspace/stream i %% inflight")
+    ap.add_argument("--inflight", type=int, default=0,
+                    help="batches in flight: batch i runs on workspace/stream i %% inflight.  Default 3 for protein batches "
+                         "(the probe kernel is bound by memory requests, the counting kernel by latency: neighbouring batches "
+                         "overlap, +32 %% throughput), 1 for nucleotide batches (their kernels fill the device: no gain) and "
+                         "in sharded mode")
     ap.add_argument("--compact", type=int, default=0,
                     help="1: finish every batch with the hit lists packed in query order (one more scan + copy pass); "
                          "0 (default): each query's list stays where the search kernel wrote it (offset + count per query)")
@@ -174,6 +177,8 @@ def main():
         args.queries = 1000000 if nucl else 10000
     if args.batches_per_step <= 0:
         args.batches_per_step = 3 if nucl else (20 if args.db == "zipf" else 200)
+    if args.inflight <= 0:
+        args.inflight = 1 if (nucl or args.mode == "sharded" or args.db == "zipf") else 3
     if args.db == "zipf":
         args.g_tier_slots = args.g_tier_slots or (1 << 30)
         args.max_hits = args.max_hits or (1 << 28)
@@ -299,6 +304,20 @@ def main():
     finish_all()
     tm = wss[0].kernel_ms_sum()
     n_calls = max(tm["calls"], 1)
+    # with several batches in flight the kernels of neighbouring batches share the device: their durations in the
+    # timed region say how the overlap went, not what a kernel can do.  A short untimed pass with ONE batch in flight
+    # gives every kernel alone on the device (reported next to the timed-region figures)
+    tm_alone = None
+    if args.inflight > 1 and not sharded_mode:
+        wss[0].set_timing(1)
+        wss[0].reset_timers()
+        for i in range(96):
+            b = i % n_distinct
+            wss[0].search_device(d_bufs[b].data_ptr(), d_offs[b].data_ptr(), args.queries, len(batches[b][0]), stream=streams[0])
+            if args.post:
+                wss[0].topn_device(0.05, 10, 10, best_start_codon=nucl, stream=streams[0])
+        wss[0].finish(streams[0])
+        tm_alone = wss[0].kernel_ms_sum()
 
     # work of the timed region = sum over the launches of their batch's exact counters
     n_timed = n_launch - first_timed
@@ -358,17 +377,29 @@ def main():
              "share_of_batch_time": secs / step_s if step_s > 0 else 0.0}
         d.update(extra or {})
         return d
+    def alone(which, nbytes):
+        if not tm_alone or not tm_alone["calls"]:
+            return {}
+        secs = tm_alone[which] / tm_alone["calls"] / 1e3
+        d = {"ms": secs * 1e3, "achieved": nbytes / secs / 1e9, "frac": nbytes / secs / 1e9 / HBM_PEAK_GBPS, "launches": tm_alone["calls"]}
+        if which == "probe_ms":
+            d["G_random_requests_per_s"] = c["n_probe"] / secs / 1e9
+        return {"alone_on_the_device": d}
     kernels = [kern("probe_kernel", probe_s, probe_bytes,
-                    {"G_random_requests_per_s": c["n_probe"] / probe_s / 1e9 if probe_s > 0 else 0.0,
-                     "random_request_ceiling_G_per_s": 53.0}),  # tools/random_read_bench.hip: 16..128-byte records alike
-               kern("count_group_kernel (+ G tier, finalize)", count_s, count_bytes)]
+                    dict({"G_random_requests_per_s": c["n_probe"] / probe_s / 1e9 if probe_s > 0 else 0.0,
+                          "random_request_ceiling_G_per_s": 52.0},  # tools/random_read_bench.hip: 16..128-byte records alike
+                         **alone("probe_ms", probe_bytes))),
+               kern("count_group_kernel (+ G tier, finalize)", count_s, count_bytes, alone("count_ms", count_bytes))]
     kernels.sort(key=lambda k: -k["ms"])
     roofline = {
         "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
         # the WHOLE batch: all algorithmic bytes of a batch / wall time per batch of the timed region
         "achieved": whole_bytes / step_s / 1e9, "frac": whole_bytes / step_s / 1e9 / HBM_PEAK_GBPS,
         "traffic": traffic,
-        "scope": "whole batch (prep [+ translation] + probe + count + G tier), wall clock of the timed region",
+        "scope": "whole batch (prep [+ translation] + probe + count + G tier), wall clock of the timed region; per-kernel "
+                 "ms are HIP-event durations inside the timed region" + (" (%d batches in flight: kernels of neighbouring "
+                 "batches overlap, `alone_on_the_device` is the same kernel with one batch in flight)" % args.inflight
+                                                                        if args.inflight > 1 else ""),
         "algorithmic_bytes_per_batch": whole_bytes,
         "bytes_per_lookup": whole_bytes / max(c["n_lookup"], 1),
         "dominant_kernel": kernels[0], "other_kernels": kernels[1:], "timed_launches": n_calls,

@@ -1215,6 +1215,9 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     if (pe != hipSuccess) { delete ws; return kaamer_fail(KAAMER_E_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(pe)); }
     if (grp_per_cu < 1) grp_per_cu = 1;
     if (p_per_cu < 1) p_per_cu = 1;
+    // tuning knobs (tools/coresident.sh): workgroups per CU of the counting / probe kernels, never above what fits
+    if (const char *e = getenv("KAAMER_GRP_PER_CU")) { const int v = atoi(e); if (v >= 1 && v < grp_per_cu) grp_per_cu = v; }
+    if (const char *e = getenv("KAAMER_P_PER_CU")) { const int v = atoi(e); if (v >= 1 && v < p_per_cu) p_per_cu = v; }
     ws->n_cu = prop.multiProcessorCount;
     ws->grp_grid = ws->n_cu * grp_per_cu;
     ws->g_grid = ws->n_cu / 2;  // the G tier is rare; its last workgroup also finalizes the batch (one atomic per workgroup)
