@@ -1418,7 +1418,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         hipLaunchKernelGGL(prep_layout_schedule_kernel, dim3(tiles), dim3(LAY_THREADS), 0, s, pl);
     } else {
         // 6-frame translation: count, scan, write, order (translate.hip.inc)
-        const size_t n6 = (size_t)n_seqs * 6, cap6 = (size_t)ws->max_seqs * 6;
+        const size_t cap6 = (size_t)ws->max_seqs * 6;
         TranslateParams tp;
         memset(&tp, 0, sizeof tp);
         tp.seqs = d_seqs; tp.offsets = d_offsets; tp.n_seqs = n_seqs;
