@@ -1462,14 +1462,14 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         tp.w_off_orf = ws->d_off3; tp.w_off_aa = ws->d_off3 + (cap6 + 1); tp.w_off_sa = ws->d_off3 + 2 * (cap6 + 1);
         // long sequences first (listed, cut in pieces, counted: a wave per piece) -- a reads-only batch falls through
         // these launches; then everything of the reads and the output offsets of both kinds in one kernel
-        hipLaunchKernelGGL(list_long_kernel, dim3((unsigned)(((uint64_t)n_seqs + 255) / 256 + (n_seqs ? 0 : 1))), dim3(256), 0, s, tp);
+        hipLaunchKernelGGL(list_long_kernel, dim3((unsigned)(((uint64_t)n_seqs + LL_BLOCK - 1) / LL_BLOCK + (n_seqs ? 0 : 1))), dim3(LL_BLOCK), 0, s, tp);
         scan_u32(ws->d_long_np, tp.n_long, n_long_bound, ws->d_piece_base);
         hipLaunchKernelGGL(translate_kernel<false>, dim3(tgrid), dim3(256), 0, s, tp);
         for (int a = 0; a < 3; a++) scan_u32(ws->d_pcnt3 + a * mpi, ws->d_n_piece_items, piece_bound, ws->d_poff3 + a * (mpi + 1));
         hipLaunchKernelGGL(long_totals_kernel, dim3((unsigned)((n_long_bound * 6 + 255) / 256)), dim3(256), 0, s, tp);
         hipLaunchKernelGGL(translate_reads_kernel, dim3(sgrid), dim3(64 * TS_WAVES), 0, s, tp);
         hipLaunchKernelGGL(translate_kernel<true>, dim3(tgrid), dim3(256), 0, s, tp);
-        hipLaunchKernelGGL(orf_order_long_kernel, dim3((unsigned)(n_long_bound < 1024 ? (n_long_bound ? n_long_bound : 1) : 1024)), dim3(256), 0, s,
+        hipLaunchKernelGGL(orf_order_long_kernel, dim3((unsigned)(n_long_bound < (uint64_t)ws->n_cu * 32 ? (n_long_bound + 3) / 4 + 1 : (uint64_t)ws->n_cu * 8)), dim3(256), 0, s,
                            ws->d_tmp_meta, tp.off_orf, ws->d_long_seq, tp.n_long, ws->d_q, ws->d_nq);
         hipLaunchKernelGGL(prep_orf_kernel, dim3(ws->n_cu * 4), dim3(pb), 0, s, ws->d_q, ws->d_nq, ws->d_valid, ws->d_n_pos,
                            ws->d_qinfo, ws->d_slots, ws->d_hit_off, ws->d_q_cnt);
