@@ -1403,7 +1403,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         // prep + table layout + group schedule: one launch (count_group.hip.inc)
         PrepLayoutParams pl;
         memset(&pl, 0, sizeof pl);
-        pl.seqs = d_seqs; pl.offsets = d_offsets; pl.n_seqs = n_seqs;
+        pl.seqs = d_seqs; pl.pos_bound = seq_bytes; pl.offsets = d_offsets; pl.n_seqs = n_seqs;
         pl.q = ws->d_q; pl.d_nq = ws->d_nq; pl.d_n_pos = ws->d_n_pos; pl.invalid = ws->d_valid; pl.qinfo = ws->d_qinfo;
         pl.hit_off = ws->d_hit_off; pl.q_cnt = ws->d_q_cnt;
         pl.E = ws->d_slot_off; pl.group_first = ws->d_group_first; pl.group_start = ws->d_group_start;
@@ -1421,7 +1421,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         const size_t cap6 = (size_t)ws->max_seqs * 6;
         TranslateParams tp;
         memset(&tp, 0, sizeof tp);
-        tp.seqs = d_seqs; tp.offsets = d_offsets; tp.n_seqs = n_seqs;
+        tp.seqs = d_seqs; tp.offsets = d_offsets; tp.n_seqs = n_seqs; tp.seq_bound = seq_bytes;
         tp.cnt_orf = ws->d_cnt3; tp.cnt_aa = ws->d_cnt3 + cap6; tp.cnt_sa = ws->d_cnt3 + 2 * cap6;
         tp.off_orf = ws->d_off3; tp.off_aa = ws->d_off3 + (cap6 + 1); tp.off_sa = ws->d_off3 + 2 * (cap6 + 1);
         tp.tmp_meta = ws->d_tmp_meta; tp.orf_aa = ws->d_orf_aa; tp.starts_alt = ws->d_starts_alt;
