@@ -138,3 +138,24 @@ def NucleotideSearch(index, fasta_text, options=None):
     for qr in out:
         qr["Query"]["Contig"] = qr["Query"]["Name"]  # search.go:305-306
     return out
+
+
+def FetchHitsInformation(query_results, proteins):
+    """search.go:454-470 for a list of QueryResult dicts: HitEntries[Key] = the Protein entry (protein.proto:
+    EntryId, Sequence, Length, Features) of every reported hit, from the protein table makedb built
+    (api.Proteins: kaamer_fetch_hits) instead of one ProteinStore point read per hit.  Like the reference, a
+    query's loop stops at the first id that has no entry."""
+    keys = sorted({h["Key"] for qr in query_results for h in qr["SearchResults"]["Hits"]})
+    entries = dict(zip(keys, proteins.fetch_hits(keys))) if keys else {}
+    for qr in query_results:
+        he = qr.setdefault("HitEntries", {})
+        for h in qr["SearchResults"]["Hits"]:
+            if h["Key"] in he:
+                continue
+            e = entries.get(h["Key"])
+            if e is None:
+                break                      # search.go:461-463: return on the first failed read
+            he[h["Key"]] = {"EntryId": e["EntryId"].decode("latin-1"), "Sequence": e["Sequence"].decode("latin-1"),
+                            "Length": e["Length"],
+                            "Features": {k.decode("latin-1"): v.decode("latin-1") for k, v in e["Features"].items()}}
+    return query_results

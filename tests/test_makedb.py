@@ -162,3 +162,18 @@ def test_protein_table_file_round_trip_and_validation(klib, tmp_path):
     path.write_bytes(bytes(hdr))
     with pytest.raises(RuntimeError):
         api.Proteins.load(path)
+
+
+def test_fetch_hits_information_on_query_results(klib):
+    """FetchHitsInformation (search.go:454-470) over the QueryResult form the drivers return"""
+    from kaamer_amd import search
+    p = api.Proteins.from_tsv(TSV)
+    qrs = [{"Query": {"Name": "q1"}, "SearchResults": {"Hits": [{"Key": 1, "Kmatch": 11}, {"Key": 0, "Kmatch": 10}]}},
+           {"Query": {"Name": "q2"}, "SearchResults": {"Hits": [{"Key": 3, "Kmatch": 14}, {"Key": 77, "Kmatch": 12}, {"Key": 2, "Kmatch": 11}]}},
+           {"Query": {"Name": "q3"}, "SearchResults": {"Hits": []}}]
+    out = search.FetchHitsInformation(qrs, p)
+    assert out[0]["HitEntries"][0] == {"EntryId": "P1", "Sequence": "MKTAYIAKQRQISTFVK", "Length": 17,
+                                       "Features": {"Organism": "E. coli", "EC": "1.1.1.1"}}
+    assert set(out[0]["HitEntries"]) == {0, 1} and out[0]["HitEntries"][1]["EntryId"] == "P4"
+    assert set(out[1]["HitEntries"]) == {3}          # the loop returns at the first id without an entry (search.go:461-463)
+    assert out[2]["HitEntries"] == {}
