@@ -99,7 +99,8 @@ static_assert(sizeof(kaamer_counters) == CTR_N * 8, "counter layout");
 enum { LIST_S = 0, LIST_L, LIST_SO, LIST_G, N_LISTS };
 // small per-batch device state after the list counters (all zeroed by the finalize step)
 enum { SLOT_QUEUE_HEAD = N_LISTS, SLOT_STATUS = N_LISTS + 1, SLOT_GROUP_QUEUE = N_LISTS + 2, SLOT_GROUP_QUEUE_POS = N_LISTS + 3,
-       SLOT_N_LONG = N_LISTS + 4, SLOT_TILES_DONE = N_LISTS + 5, SLOT_TR_TICKET = N_LISTS + 6, N_SMALL_SLOTS = N_LISTS + 7 };
+       SLOT_N_LONG = N_LISTS + 4, SLOT_TILES_DONE = N_LISTS + 5, SLOT_TR_TICKET = N_LISTS + 6,
+       SLOT_QUEUE_SUB = N_LISTS + 7 /* 8 words */, N_SMALL_SLOTS = N_LISTS + 15 };
 // one entry: everything a tier needs to start on a query, in one 16-byte load
 struct alignas(16) WorkItem {
     uint32_t q;
@@ -111,7 +112,7 @@ struct alignas(16) WorkItem {
 #define MAX_TIMED_CALLS 1024u
 #define L_WAVES 8
 #define L_LOG2CAP 12
-#define G_WAVES 16
+#define G_WAVES 4
 #ifndef S_MIN_WAVES
 #define S_MIN_WAVES 1
 #endif
@@ -366,7 +367,7 @@ struct CountParams {
     uint64_t hit_cap;                 // entries of the hit arrays
     unsigned long long *tail_cursor;  // entries handed out after E[n_queries] (G tier)
     // G tier arena
-    uint32_t *g_keys, *g_cnt, *g_min;
+    uint32_t *g_keys;  // G-tier tables: 16-byte slots {protein id, count, lowest position, -}
     uint64_t g_slots;
     unsigned long long *g_cursor;
     uint32_t n_proteins;
@@ -418,23 +419,31 @@ template <int LOG2CAP, bool FIRSTPOS = true> struct LdsTable {
     __device__ __forceinline__ bool over_limit() const { return *(volatile uint32_t *)nd > LIMIT; }
 };
 
+// A slot is 16 bytes {protein id, count, lowest position, -}: one memory line per table add.  As three arrays an add
+// touched three random lines of a table that is megabytes large, and the tier ran at the speed of those line fills and
+// write-backs (14 ms per batch on the skewed database, 53 GB of traffic).
 struct GlobalTable {
-    uint32_t *keys, *cnt, *minpos, *nd;  // nd lives in LDS
+    uint32_t *slots;  // 4 words per slot
+    uint32_t *nd;     // nd lives in LDS
     uint32_t log2cap;
+    // One workgroup owns the table (its region comes from a cursor, once per batch), so the adds are atomics at
+    // WORKGROUP scope: performed in the L2 of the XCD the workgroup runs on, where the plain 16-byte stores of the
+    // initialisation went (the L1 is write-through and holds no line of the table: nothing ever loads one before the
+    // final read-out).
     __device__ __forceinline__ bool add_n(uint32_t pid, uint32_t pos, uint32_t n, uint32_t &nnew) const
     {
         const uint32_t mask = (1u << log2cap) - 1u;
         uint32_t h = (pid * 0x9E3779B1u) >> (32 - log2cap);
         for (uint32_t t = 0; t <= mask; t++) {
-            uint32_t k = __hip_atomic_load(&keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (k == KH_EMPTY_PID) {
-                const uint32_t old = atomicCAS(&keys[h], KH_EMPTY_PID, pid);
-                if (old == KH_EMPTY_PID) { nnew++; k = pid; }
-                else k = old;
+            uint32_t *sl = slots + 4ull * h;
+            uint32_t k = KH_EMPTY_PID;  // expected; receives what the slot holds when it is not empty
+            if (__hip_atomic_compare_exchange_strong(&sl[0], &k, pid, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                nnew++;
+                k = pid;
             }
             if (k == pid) {
-                atomicAdd(&cnt[h], n);
-                atomicMin(&minpos[h], pos);
+                __hip_atomic_fetch_add(&sl[1], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_min(&sl[2], pos, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 return true;
             }
             h = (h + 1u) & mask;
@@ -477,10 +486,22 @@ __device__ __forceinline__ bool add_runs(const Table &tab, uint32_t x, uint32_t 
 // increments (KCombStore.Get + the id loop of search.go:427-436).  Window k starts at
 // c0 + k*stride.  `s_pref` is 64 words of LDS private to the wave.  No workgroup
 // barriers inside.  COUNT_ONLY: only sum the postings (G tier sizing pass).
+// G tier: postings lists of more than LONG_LIST ids are not expanded by the wave that meets them: they go on a list in
+// LDS and the whole workgroup expands them afterwards, FLAT -- item t of all the lists together belongs to the list found
+// by binary search in the prefix of their lengths -- a thread per id.  One wave walking a 9 000-protein list 64 ids at a
+// time, for each of the 21 positions of a shared motif, is 3 000 dependent round trips while fifteen waves wait.
+#define LONG_LIST 8u
+#define LONG_SINK_CAP 2048u
+struct LongSink {
+    uint32_t n;
+    uint32_t off[LONG_SINK_CAP], pos[LONG_SINK_CAP], cnt[LONG_SINK_CAP];  // cnt becomes the exclusive prefix
+    uint32_t total;
+};
+
 template <class Table, int NWIN, bool COUNT_ONLY>
 __device__ __forceinline__ bool count_windows(const CountParams &p, const uint32_t *vals,
                                               int32_t size, int32_t c0, int32_t stride, const Table &tab, PostCtr &c,
-                                              volatile uint32_t *s_pref)
+                                              volatile uint32_t *s_pref, LongSink *sink = nullptr)
 {
     const uint32_t lane = lane_id();
     uint32_t v[NWIN];
@@ -494,6 +515,15 @@ __device__ __forceinline__ bool count_windows(const CountParams &p, const uint32
             v[k] = vals[pos];
             if (v[k] & KH_INLINE_BIT) h[k] = make_uint4(1u, v[k] & ~KH_INLINE_BIT, 0, 0);
             else if (v[k] != 0u) h[k] = reinterpret_cast<const uint4 *>(p.arena)[v[k]];  // {count, id0, id1, id2}
+        }
+        if (!COUNT_ONLY && sink && h[k].x > LONG_LIST) {
+            const uint32_t slot = atomicAdd(&sink->n, 1u);
+            if (slot < LONG_SINK_CAP) {  // (a full list: the wave expands it itself, below)
+                sink->off[slot] = v[k]; sink->pos[slot] = (uint32_t)pos; sink->cnt[slot] = h[k].x;
+                c.post += h[k].x; c.lists++; c.lids += h[k].x;
+                h[k] = make_uint4(0, 0, 0, 0);
+                v[k] = 0u;
+            }
         }
     }
     bool ok = true;
@@ -644,6 +674,7 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
     constexpr int NWIN = 2;
     __shared__ uint32_t s_pref[WAVES][NWIN * 64];
     __shared__ unsigned long long s_post, s_off, s_base;
+    __shared__ LongSink s_long;
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint32_t n_items = *p.list_count < p.list_cap ? *p.list_count : p.list_cap;
@@ -657,7 +688,7 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
         const uint32_t q = wi.q;
         const int32_t size = wi.size;
         const uint32_t *vals = p.vals + wi.aa_off;
-        if (tid == 0) { s_nd = 0; s_fail = 0; s_post = 0; s_cursor = 0; }
+        if (tid == 0) { s_nd = 0; s_fail = 0; s_post = 0; s_cursor = 0; s_long.n = 0; }
         __syncthreads();
         // pass 1: exact number of postings (an upper bound of the distinct proteins)
         pc.clear();
@@ -686,21 +717,53 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
             continue;
         }
         GlobalTable gt;
-        gt.keys = p.g_keys + off; gt.cnt = p.g_cnt + off; gt.minpos = p.g_min + off; gt.nd = &s_nd; gt.log2cap = log2cap;
+        gt.slots = p.g_keys + 4ull * off; gt.nd = &s_nd; gt.log2cap = log2cap;
         // The table is only ever touched with device-scope atomics (initialisation included), which
         // are performed past the L2: no agent-scope fence -- a full L2 write-back on this part -- is
         // needed between the phases, a workgroup barrier (which drains vmcnt) is enough.
-        for (unsigned long long i = tid; i < cap; i += 64 * WAVES) {
-            __hip_atomic_store(&gt.keys[i], KH_EMPTY_PID, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&gt.cnt[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&gt.minpos[i], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        for (unsigned long long i = tid; i < cap; i += 64 * WAVES)
+            reinterpret_cast<uint4 *>(gt.slots)[i] = make_uint4(KH_EMPTY_PID, 0u, 0xFFFFFFFFu, 0u);
         __syncthreads();
         // pass 2: count
         pc.clear();
         for (int32_t r0 = 0; r0 < size; r0 += 64 * WAVES * NWIN) {
             const bool ok = count_windows<GlobalTable, NWIN, false>(p, vals, size, r0 + 64 * (int32_t)wv, 64 * WAVES, gt,
-                                                                   pc, s_pref[wv]);
+                                                                   pc, s_pref[wv], &s_long);
+            if (!ok) s_fail = 1;
+        }
+        __syncthreads();
+        {   // the long postings lists the sweep set aside
+            const uint32_t nl = s_long.n < LONG_SINK_CAP ? s_long.n : LONG_SINK_CAP;
+            if (wv == 0 && nl) {  // lengths -> exclusive prefix (32 entries per lane)
+                constexpr uint32_t PER = LONG_SINK_CAP / 64;
+                uint32_t sum = 0;
+                for (uint32_t i = 0; i < PER; i++) { const uint32_t e = lane * PER + i; sum += e < nl ? s_long.cnt[e] : 0u; }
+                uint32_t inc = sum;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t t = __shfl_up(inc, o, 64);
+                    if ((int)lane >= o) inc += t;
+                }
+                uint32_t run = inc - sum;
+                for (uint32_t i = 0; i < PER; i++) {
+                    const uint32_t e = lane * PER + i;
+                    if (e < nl) { const uint32_t c = s_long.cnt[e]; s_long.cnt[e] = run; run += c; }
+                }
+                if (lane == 63) s_long.total = inc;
+            }
+            __syncthreads();
+            uint32_t nnew = 0;
+            bool ok = true;
+            const uint32_t total = nl ? s_long.total : 0u;
+            for (uint32_t t = tid; t < total; t += 64 * WAVES) {
+                uint32_t e = 0;  // largest e with prefix[e] <= t
+#pragma unroll
+                for (uint32_t sft = LONG_SINK_CAP / 2; sft > 0; sft >>= 1)
+                    if (e + sft < nl && s_long.cnt[e + sft] <= t) e += sft;
+                ok = gt.add_n(p.arena[(uint64_t)s_long.off[e] * 4 + 1 + (t - s_long.cnt[e])], s_long.pos[e], 1u, nnew) && ok;
+            }
+            const uint32_t wn = wave_total(nnew);
+            if (lane == 0 && wn) atomicAdd(&s_nd, wn);
             if (!ok) s_fail = 1;
         }
         __syncthreads();
@@ -715,18 +778,28 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
         __syncthreads();
         const unsigned long long base = s_base;
         if (base != ~0ull && total > 0) {
-            for (unsigned long long i0 = (unsigned long long)wv * 64; i0 < cap; i0 += 64 * WAVES) {
-                const uint32_t k = __hip_atomic_load(&gt.keys[i0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const bool has = k != KH_EMPTY_PID;
-                const unsigned long long bm = __ballot(has);
-                uint32_t wbase = 0;
-                if (lane == 0 && bm) wbase = atomicAdd(&s_cursor, (uint32_t)__popcll(bm));
-                wbase = __shfl(wbase, 0, 64);
-                if (has) {
-                    const uint32_t idx = wbase + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull));
-                    p.hit_pid[base + idx] = k;
-                    p.hit_km[base + idx] = __hip_atomic_load(&gt.cnt[i0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    p.hit_fp[base + idx] = __hip_atomic_load(&gt.minpos[i0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // four stripes of the table per round trip, a 16-byte slot per lane
+            for (unsigned long long i0 = (unsigned long long)wv * 64; i0 < cap; i0 += 4ull * 64 * WAVES) {
+                uint32_t k4[4], c4[4], m4[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const unsigned long long i = i0 + (unsigned long long)u * 64 * WAVES + lane;
+                    const uint4 sv = reinterpret_cast<const uint4 *>(gt.slots)[i < cap ? i : cap - 1];
+                    k4[u] = i < cap ? sv.x : KH_EMPTY_PID; c4[u] = sv.y; m4[u] = sv.z;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const bool has = k4[u] != KH_EMPTY_PID;
+                    const unsigned long long bm = __ballot(has);
+                    uint32_t wbase = 0;
+                    if (lane == 0 && bm) wbase = atomicAdd(&s_cursor, (uint32_t)__popcll(bm));
+                    wbase = __shfl(wbase, 0, 64);
+                    if (has) {
+                        const uint32_t idx = wbase + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull));
+                        p.hit_pid[base + idx] = k4[u];
+                        p.hit_km[base + idx] = c4[u];
+                        p.hit_fp[base + idx] = m4[u];
+                    }
                 }
             }
             if (wv == 0) tot_hits += total;
@@ -743,7 +816,14 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
         __shared__ uint32_t s_last;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this wave's counter atomics are done
         __syncthreads();
-        if (tid == 0) s_last = atomicAdd(p.queue_head, 1u) == gridDim.x - 1u;
+        // two levels: 512 workgroups bumping ONE word serialise at ~90 per microsecond (6 us of a 0.2 ms batch);
+        // eight sub-counters (workgroup index mod 8), and the last arrival of each bumps the top one
+        if (tid == 0) {
+            const uint32_t sub = blockIdx.x & 7u, n_sub = (gridDim.x - sub + 7u) >> 3, n_top = gridDim.x < 8u ? gridDim.x : 8u;
+            s_last = 0;
+            if (atomicAdd(p.queue_head + (SLOT_QUEUE_SUB - SLOT_QUEUE_HEAD) + sub, 1u) == n_sub - 1u)
+                s_last = atomicAdd(p.queue_head, 1u) == n_top - 1u;
+        }
         __syncthreads();
         if (s_last) {
             finalize_body<true>(p.counters, p.fin_out, p.fin_small, p.fin_status_out, p.fin_cursors);
@@ -754,7 +834,7 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
 // PositionHits of the G-tier queries (search.go:442-452): the query's final hit list goes into a
 // table in HBM (id -> index in the list), then every (position, id) sets one bit of that hit's bitmap.
 struct BitsTable {
-    const uint32_t *keys, *idx;
+    const uint32_t *slots;  // 4 words per slot: {protein id, index in the hit list, -, -}
     uint32_t *nd;
     uint32_t log2cap, words;
     unsigned long long *bits;  // first bitmap of the query
@@ -763,9 +843,9 @@ struct BitsTable {
         const uint32_t mask = (1u << log2cap) - 1u;
         uint32_t h = (pid * 0x9E3779B1u) >> (32 - log2cap);
         for (uint32_t t = 0; t <= mask; t++) {
-            const uint32_t k = __hip_atomic_load(&keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t k = __hip_atomic_load(&slots[4ull * h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (k == pid) {
-                unsigned long long *bm = bits + (unsigned long long)__hip_atomic_load(&idx[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * words;
+                unsigned long long *bm = bits + (unsigned long long)__hip_atomic_load(&slots[4ull * h + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * words;
                 const uint32_t w0 = pos >> 6, b0 = pos & 63u;
                 const uint32_t n0 = n < 64u - b0 ? n : 64u - b0;
                 atomicOr(&bm[w0], (n0 == 64u ? ~0ull : ((1ull << n0) - 1ull)) << b0);
@@ -807,19 +887,19 @@ __global__ __launch_bounds__(64 * G_WAVES) void positions_global_kernel(CountPar
         __syncthreads();
         const unsigned long long off = s_off;
         if (off == ~0ull || cnt == 0 || size <= 0) { __syncthreads(); continue; }
-        uint32_t *keys = p.g_keys + off, *idx = p.g_cnt + off;
-        for (unsigned long long i = tid; i < cap; i += 64 * WAVES) __hip_atomic_store(&keys[i], KH_EMPTY_PID, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t *slots = p.g_keys + 4ull * off;
+        for (unsigned long long i = tid; i < cap; i += 64 * WAVES) __hip_atomic_store(&slots[4 * i], KH_EMPTY_PID, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         const uint32_t mask = (uint32_t)cap - 1u;
         for (uint32_t i = tid; i < cnt; i += 64 * WAVES) {
             const uint32_t pid = p.hit_pid[hoff + i];
             uint32_t h = (pid * 0x9E3779B1u) >> (32 - log2cap);
-            while (atomicCAS(&keys[h], KH_EMPTY_PID, pid) != KH_EMPTY_PID) h = (h + 1u) & mask;  // ids are distinct, load <= 0.5
-            __hip_atomic_store(&idx[h], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            while (atomicCAS(&slots[4ull * h], KH_EMPTY_PID, pid) != KH_EMPTY_PID) h = (h + 1u) & mask;  // ids are distinct, load <= 0.5
+            __hip_atomic_store(&slots[4ull * h + 1], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
         BitsTable bt;
-        bt.keys = keys; bt.idx = idx; bt.nd = &s_nd; bt.log2cap = log2cap;
+        bt.slots = slots; bt.nd = &s_nd; bt.log2cap = log2cap;
         bt.words = ((uint32_t)size + 63u) >> 6;
         bt.bits = p.pos_bits + p.pos_base[q];
         pc.clear();
@@ -1056,7 +1136,7 @@ struct kaamer_workspace {
     uint64_t *d_pos_base;               // exclusive scan of the above
     uint64_t *d_pos_off;                // per hit: first word of its bitmap
     unsigned long long *d_pos_bits;
-    uint32_t *d_g_keys, *d_g_cnt, *d_g_min;
+    uint32_t *d_g_keys;
     unsigned long long *d_counter_replicas;
     kaamer_counters *d_counters;
     uint64_t *d_bsum;
@@ -1155,7 +1235,7 @@ void kaamer_workspace_free(kaamer_workspace *ws)
                      ws->d_tmp_meta, ws->d_orf_aa, ws->d_starts_alt, ws->d_q_cnt, ws->d_csr_off, ws->d_c_pid, ws->d_c_km, ws->d_c_fp,
                      ws->d_pool_cursor, ws->d_lists, ws->d_list_counts, ws->d_status_out, ws->d_qinfo, ws->d_slots,
                      ws->d_slot_off, ws->d_group_first, ws->d_n_groups, ws->d_pos_words, ws->d_pos_base, ws->d_pos_off, ws->d_pos_bits, ws->d_g_keys,
-                     ws->d_g_cnt, ws->d_g_min, ws->d_counter_replicas, ws->d_counters, ws->d_bsum, ws->d_chain, ws->d_tr_chain, ws->d_sched, ws->d_n_sched, ws->d_group_start, ws->d_lay_total, ws->d_top_cnt, ws->d_top_pid, ws->d_top_km, ws->d_top_fp, ws->d_top_trim, ws->d_top_start, ws->d_top_size, ws->d_rep_flag, ws->d_rep_aalen, ws->d_rep_query, ws->d_rep_pid, ws->d_rep_km, ws->d_rep_fp, ws->d_rep_trim, ws->d_rep_rank, ws->d_rep_eoff, ws->d_rep_aoff, ws->d_rep_off, ws->d_rep_q, ws->d_rep_aa, ws->d_hit_off,
+                     ws->d_counter_replicas, ws->d_counters, ws->d_bsum, ws->d_chain, ws->d_tr_chain, ws->d_sched, ws->d_n_sched, ws->d_group_start, ws->d_lay_total, ws->d_top_cnt, ws->d_top_pid, ws->d_top_km, ws->d_top_fp, ws->d_top_trim, ws->d_top_start, ws->d_top_size, ws->d_rep_flag, ws->d_rep_aalen, ws->d_rep_query, ws->d_rep_pid, ws->d_rep_km, ws->d_rep_fp, ws->d_rep_trim, ws->d_rep_rank, ws->d_rep_eoff, ws->d_rep_aoff, ws->d_rep_off, ws->d_rep_q, ws->d_rep_aa, ws->d_hit_off,
                      ws->d_hit_pid, ws->d_hit_km, ws->d_hit_fp, ws->d_x_dst_off, ws->d_x_src_off, ws->d_x_nq_owned, ws->d_x_pid, ws->d_x_km, ws->d_x_fp, ws->d_x_ent_off };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (ws->ev) {
@@ -1220,7 +1300,9 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     if (const char *e = getenv("KAAMER_P_PER_CU")) { const int v = atoi(e); if (v >= 1 && v < p_per_cu) p_per_cu = v; }
     ws->n_cu = prop.multiProcessorCount;
     ws->grp_grid = ws->n_cu * grp_per_cu;
-    ws->g_grid = ws->n_cu / 2;  // the G tier is rare; its last workgroup also finalizes the batch (one atomic per workgroup)
+    // the G tier is rare on a database like DB-SP, but with a skewed database 15 % of the queries overflow their LDS
+    // table: enough workgroups to keep the memory system busy (the last one to finish also finalizes the batch)
+    ws->g_grid = ws->n_cu * 2;
     ws->p_grid = ws->n_cu * p_per_cu;
     // a table has at most max(64, 3 x SizeInKmer) slots
     {
@@ -1287,9 +1369,7 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
         if (!rc) rc = dev_alloc(&ws->d_pos_off, ws->sparse_cap);
         if (!rc) rc = dev_alloc(&ws->d_pos_bits, ws->bits_cap);
     }
-    if (!rc) rc = dev_alloc(&ws->d_g_keys, ws->g_slots);
-    if (!rc) rc = dev_alloc(&ws->d_g_cnt, ws->g_slots);
-    if (!rc) rc = dev_alloc(&ws->d_g_min, ws->g_slots);
+    if (!rc) rc = dev_alloc(&ws->d_g_keys, 4 * ws->g_slots);  // 16-byte slots {id, count, lowest position, -}
     if (!rc) rc = dev_alloc(&ws->d_counter_replicas, (size_t)CTR_REPLICAS * CTR_N);
     if (!rc) rc = dev_alloc(&ws->d_counters, 1);
     if (!rc) rc = dev_alloc(&ws->d_bsum, ws->n_scan_blocks);
@@ -1523,8 +1603,6 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     p.hit_cap = ws->sparse_cap;
     p.tail_cursor = ws->d_pool_cursor;
     p.g_keys = ws->d_g_keys;
-    p.g_cnt = ws->d_g_cnt;
-    p.g_min = ws->d_g_min;
     p.g_slots = ws->g_slots;
     p.g_cursor = ws->d_pool_cursor + CURSOR_STRIDE;
     p.n_proteins = ix->hdr.max_protein_id + 1u ? ix->hdr.max_protein_id + 1u : 0xFFFFFFFFu;
@@ -1652,7 +1730,7 @@ static int merge_device_impl(kaamer_workspace *ws, const uint64_t *d_ent_off, co
     p.hit_pid = ws->d_hit_pid; p.hit_km = ws->d_hit_km; p.hit_fp = ws->d_hit_fp;
     p.hit_cap = ws->sparse_cap;
     p.tail_cursor = ws->d_pool_cursor;
-    p.g_keys = ws->d_g_keys; p.g_cnt = ws->d_g_cnt; p.g_min = ws->d_g_min;
+    p.g_keys = ws->d_g_keys;
     p.g_slots = ws->g_slots;
     p.g_cursor = ws->d_pool_cursor + CURSOR_STRIDE;
     p.counters = ws->d_counter_replicas;
