@@ -364,7 +364,8 @@ def main():
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
         for e in pm["runs"]:
-            if (e["db_proteins"], e["queries"], e["workload"], e["db"]) == (args.db_proteins, args.queries, args.workload, args.db):
+            if (e["db_proteins"], e["queries"], e["workload"], e["db"]) == (args.db_proteins, args.queries, args.workload, args.db) \
+                    and not (sharded_mode or args.post or args.compact):
                 traffic = e["traffic_bytes_per_batch"]
     except Exception:
         pass
