@@ -92,8 +92,22 @@ def test_reads_edge_cases(small, oracle):
               b"GCA" * 200,                          # one ORF spanning four 64-codon chunks, no stop
               (b"ATG" + b"GCA" * 30 + b"TAG") * 8,  # repeated ORFs
               b"N" * 150, b"GCANNN" * 40]
+    # the lane-per-read kernel's limits (reads of up to 192 nt, three ORFs queued per frame of 64 codons): three
+    # 21-codon ORFs back to back in one frame, on either strand, in every frame; two ORFs that touch (the second
+    # opens on the codon after the first one's stop); unknown codons inside an ORF; a 64-codon ORF with 64 starts
+    def revcomp(s):
+        return s[::-1].translate(bytes.maketrans(b"ACGT", b"TGCA"))
+    orf21 = b"ATG" + b"GCA" * 19 + b"TAA"
+    three = orf21 * 3
+    reads += [three + b"AC", b"A" + three + b"C", b"AC" + three + b"A", three + b"ACG",
+              revcomp(three + b"AC"), revcomp(b"A" + three + b"C"), revcomp(b"AC" + three + b"A"),
+              orf21 + b"TTG" + b"GCA" * 19 + b"TGA" + b"CTG" + b"GCA" * 20,         # alternative starts, open last ORF
+              b"ATG" + b"GCANNA" * 4 + b"GCA" * 14 + b"TAA" + b"GC",               # unknown codons do not count
+              b"ATG" * 64, revcomp(b"ATG" * 64), b"ATGTTG" * 32, (b"GTG" + b"GCA" * 20 + b"TAG") * 2 + b"GTGGCA" * 9]
+    assert max(len(r) for r in reads[-13:]) <= 192
     res = ix.search(reads, seq_type=abi.READS)
-    _check_reads(res, reads, oracle, oix)
+    n = _check_reads(res, reads, oracle, oix)
+    assert sum(len(oracle.get_orfs(r)) >= 3 for r in reads[-13:]) >= 6
 
 
 def test_contig_many_orfs(small, oracle):
