@@ -1501,7 +1501,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         const size_t cap6 = (size_t)ws->max_seqs * 6;
         TranslateParams tp;
         memset(&tp, 0, sizeof tp);
-        tp.seqs = d_seqs; tp.offsets = d_offsets; tp.n_seqs = n_seqs; tp.seq_bound = seq_bytes;
+        tp.seqs = d_seqs; tp.offsets = d_offsets; tp.n_seqs = n_seqs; tp.seq_bound = seq_bytes; tp.max_long = ws->max_long; tp.max_piece_items = ws->max_piece_items;
         tp.cnt_orf = ws->d_cnt3; tp.cnt_aa = ws->d_cnt3 + cap6; tp.cnt_sa = ws->d_cnt3 + 2 * cap6;
         tp.off_orf = ws->d_off3; tp.off_aa = ws->d_off3 + (cap6 + 1); tp.off_sa = ws->d_off3 + 2 * (cap6 + 1);
         tp.tmp_meta = ws->d_tmp_meta; tp.orf_aa = ws->d_orf_aa; tp.starts_alt = ws->d_starts_alt;

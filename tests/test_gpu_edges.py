@@ -152,7 +152,13 @@ def test_device_offsets_that_disagree_with_the_batch_size(klib, oracle, gpu_devi
     bad_end = offs.copy(); bad_end[-1] += 4096            # the last sequence claims bytes the batch does not have
     bad_mid = offs.copy(); bad_mid[5] = bad_mid[7] + 3    # not ascending
     huge = offs.copy(); huge[3:] += np.uint64(1 << 40)
-    for bad in (bad_end, bad_mid, huge):
+    # overlapping ranges: every other "sequence" is 2 000 bytes long and starts 10 bytes after the previous one -- far more
+    # long sequences (and residues) than a batch of this size can hold
+    over = offs.copy()
+    over[0::2] = np.arange(len(over[0::2]), dtype=np.uint64) * 10
+    over[1::2] = over[0::2][:len(over[1::2])] + np.uint64(min(2000, len(buf) - 10 * len(over)))
+    over = np.minimum(over, np.uint64(len(buf)))
+    for bad in (bad_end, bad_mid, huge, over):
         d_off = torch.from_numpy(bad.view(np.int64)).cuda()
         ws.search_device(d_buf.data_ptr(), d_off.data_ptr(), len(seqs), len(buf), stream=stream)
         with pytest.raises(abi.KaamerError) as e:
