@@ -1095,7 +1095,7 @@ struct kaamer_workspace {
     // long sequences (> TS_MAX nt) are translated piece-wise: list, pieces per frame, per-piece counts and their scans
     uint32_t max_long;
     uint64_t max_piece_items;
-    uint32_t *d_long_seq, *d_long_np, *d_pcnt3, *d_n_piece_items;
+    uint32_t *d_long_seq, *d_long_np, *d_pcnt3, *d_n_piece_items, *d_piece_li;
     uint64_t *d_piece_base, *d_poff3;
     kaamer_query_meta *d_tmp_meta;
     uint8_t *d_orf_aa;
@@ -1231,7 +1231,7 @@ void kaamer_workspace_free(kaamer_workspace *ws)
 {
     if (!ws) return;
     (void)hipSetDevice(ws->device);
-    void *bufs[] = { ws->d_q, ws->d_nq, ws->d_n_pos, ws->d_valid, ws->d_vals, ws->d_cnt3, ws->d_off3, ws->d_n6, ws->d_long_seq, ws->d_long_np, ws->d_pcnt3, ws->d_n_piece_items, ws->d_piece_base, ws->d_poff3,
+    void *bufs[] = { ws->d_q, ws->d_nq, ws->d_n_pos, ws->d_valid, ws->d_vals, ws->d_cnt3, ws->d_off3, ws->d_n6, ws->d_long_seq, ws->d_long_np, ws->d_pcnt3, ws->d_n_piece_items, ws->d_piece_li, ws->d_piece_base, ws->d_poff3,
                      ws->d_tmp_meta, ws->d_orf_aa, ws->d_starts_alt, ws->d_q_cnt, ws->d_csr_off, ws->d_c_pid, ws->d_c_km, ws->d_c_fp,
                      ws->d_pool_cursor, ws->d_lists, ws->d_list_counts, ws->d_status_out, ws->d_qinfo, ws->d_slots,
                      ws->d_slot_off, ws->d_group_first, ws->d_n_groups, ws->d_pos_words, ws->d_pos_base, ws->d_pos_off, ws->d_pos_bits, ws->d_g_keys,
@@ -1334,6 +1334,7 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
         if (!rc) rc = dev_alloc(&ws->d_off3, 3 * (n6 + 1));
         if (!rc) rc = dev_alloc(&ws->d_n6, 1);
         if (!rc) rc = dev_alloc(&ws->d_long_seq, (size_t)ws->max_long + 1);
+        if (!rc) rc = dev_alloc(&ws->d_piece_li, (size_t)ws->max_piece_items / 6 + 2);
         if (!rc) rc = dev_alloc(&ws->d_long_np, (size_t)ws->max_long + 1);
         if (!rc) rc = dev_alloc(&ws->d_piece_base, (size_t)ws->max_long + 2);
         if (!rc) rc = dev_alloc(&ws->d_pcnt3, 3 * (size_t)ws->max_piece_items);
@@ -1512,7 +1513,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         if ((uint64_t)sgrid * TS_WAVES * 64 > (uint64_t)n_seqs) sgrid = n_seqs > 0 ? (int)(((uint64_t)n_seqs + TS_WAVES * 64 - 1) / (TS_WAVES * 64)) : 1;
         tp.n_long = ws->d_list_counts + SLOT_N_LONG;
         const size_t mpi = (size_t)ws->max_piece_items;
-        tp.long_seq = ws->d_long_seq; tp.long_np = ws->d_long_np; tp.piece_base = ws->d_piece_base;
+        tp.long_seq = ws->d_long_seq; tp.long_np = ws->d_long_np; tp.piece_base = ws->d_piece_base; tp.piece_li = ws->d_piece_li;
         tp.pcnt_orf = ws->d_pcnt3; tp.pcnt_aa = ws->d_pcnt3 + mpi; tp.pcnt_sa = ws->d_pcnt3 + 2 * mpi;
         tp.poff_orf = ws->d_poff3; tp.poff_aa = ws->d_poff3 + (mpi + 1); tp.poff_sa = ws->d_poff3 + 2 * (mpi + 1);
         tp.d_n_piece_items = ws->d_n_piece_items;
@@ -1544,6 +1545,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         // these launches; then everything of the reads and the output offsets of both kinds in one kernel
         hipLaunchKernelGGL(list_long_kernel, dim3((unsigned)(((uint64_t)n_seqs + LL_BLOCK - 1) / LL_BLOCK + (n_seqs ? 0 : 1))), dim3(LL_BLOCK), 0, s, tp);
         scan_u32(ws->d_long_np, tp.n_long, n_long_bound, ws->d_piece_base);
+        hipLaunchKernelGGL(piece_li_kernel, dim3((unsigned)((n_long_bound + 255) / 256)), dim3(256), 0, s, tp);
         hipLaunchKernelGGL(translate_kernel<false>, dim3(tgrid), dim3(256), 0, s, tp);
         for (int a = 0; a < 3; a++) scan_u32(ws->d_pcnt3 + a * mpi, ws->d_n_piece_items, piece_bound, ws->d_poff3 + a * (mpi + 1));
         hipLaunchKernelGGL(long_totals_kernel, dim3((unsigned)((n_long_bound * 6 + 255) / 256)), dim3(256), 0, s, tp);
