@@ -177,3 +177,56 @@ def test_fetch_hits_information_on_query_results(klib):
     assert set(out[0]["HitEntries"]) == {0, 1} and out[0]["HitEntries"][1]["EntryId"] == "P4"
     assert set(out[1]["HitEntries"]) == {3}          # the loop returns at the first id without an entry (search.go:461-463)
     assert out[2]["HitEntries"] == {}
+
+
+def test_random_tsv_and_nasty_fasta_against_the_restatement(klib):
+    """random bytes in every role: CR, empty fields, repeated and missing columns, '>' inside lines, no final newline"""
+    rng = np.random.default_rng(23)
+    pool = [b"MKTAYIAKQRQISTFVK", b"mktayiak", b"ACDEF", b"", b"ACDEFGHIKLMNPQRSTVWY.*XB", b"A" * 7, b"A" * 6, b"  MKTAYIAKQR  "]
+    ids = [b"P1", b"", b"sp|Q|x y", b"dup", b"dup"]
+    for trial in range(40):
+        ncol = int(rng.integers(2, 6))
+        header = [b"EntryID", b"Sequence", b"Organism", b"EC", b"Note"][:ncol]
+        if trial % 5 == 1:
+            header[0] = b"ENTRYID"
+        if trial % 5 == 2:
+            header = header[::-1]
+        rows = []
+        for _ in range(int(rng.integers(0, 25))):
+            n = int(rng.integers(1, ncol + 2))                      # short rows and rows with one column too many
+            cells = []
+            for c in range(n):
+                role = header[c].lower() if c < ncol else b""
+                if role == b"entryid":
+                    cells.append(ids[int(rng.integers(0, len(ids)))])
+                elif role == b"sequence":
+                    cells.append(pool[int(rng.integers(0, len(pool)))])
+                else:
+                    cells.append([b"x", b"", b"a b", b"1.1.1.1"][int(rng.integers(0, 4))])
+            rows.append(b"\t".join(cells))
+        eol = b"\r\n" if trial % 3 == 0 else b"\n"
+        text = eol.join([b"\t".join(header)] + rows) + (eol if trial % 2 else b"")
+        ref = _makedb_ref().run_tsv(text)
+        p = api.Proteins.from_tsv(text)
+        buf, offs = p.packed
+        got = [(int(i), bytes(buf[int(offs[j]):int(offs[j + 1])])) for j, i in enumerate(p.ids)]
+        assert got == [(r[0], r[2]) for r in ref], text
+        ents = p.fetch_hits([r[0] for r in ref])
+        for e, r in zip(ents, ref):
+            assert (e["EntryId"], e["Features"]) == (r[1], r[3]), text
+    for trial in range(40):
+        lines = []
+        for _ in range(int(rng.integers(0, 30))):
+            k = int(rng.integers(0, 8))
+            lines.append([b">id name, partial", b">id2", b"> leading space", b"MKTAYIAKQRQISTFVK", b"mk>tay", b"ACD", b"X" * 30,
+                          b">a b c, partial cds"][k])
+        eol = b"\r\n" if trial % 3 == 0 else b"\n"
+        text = eol.join(lines) + (eol if trial % 2 else b"")
+        ref = _makedb_ref().run_fasta(text)
+        p = api.Proteins.from_fasta(text)
+        buf, offs = p.packed
+        got = [(int(i), bytes(buf[int(offs[j]):int(offs[j + 1])])) for j, i in enumerate(p.ids)]
+        assert got == [(r[0], r[2]) for r in ref], text
+        last = {r[0]: r for r in ref}
+        for e, i in zip(p.fetch_hits(sorted(last)), sorted(last)):
+            assert (e["EntryId"], e["Features"][b"ProteinName"]) == (last[i][1], last[i][3][b"ProteinName"]), text
