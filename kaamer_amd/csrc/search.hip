@@ -419,6 +419,44 @@ template <int LOG2CAP, bool FIRSTPOS = true> struct LdsTable {
     __device__ __forceinline__ bool over_limit() const { return *(volatile uint32_t *)nd > LIMIT; }
 };
 
+// The G tier's first attempt: a table of 8192 slots in LDS (64 KB: protein id | count in the low and lowest position in the
+// high 16 bits of one word, so the query must be shorter than 65 535 k-mers).  A query of a skewed database that overflows
+// its group table typically has a few thousand distinct hits behind tens of thousands of postings: here those postings
+// are LDS atomics instead of line fills and write-backs of a multi-megabyte table in HBM.
+#define BIG_LOG2CAP 13
+struct BigLdsTable {
+    uint32_t *keys, *val, *nd;
+    static constexpr uint32_t CAP = 1u << BIG_LOG2CAP;
+    static constexpr uint32_t LIMIT = CAP - CAP / 4;  // keep 25 % free
+    __device__ __forceinline__ bool add_n(uint32_t pid, uint32_t pos, uint32_t n, uint32_t &nnew) const
+    {
+        uint32_t h = (pid * 0x9E3779B1u) >> (32 - BIG_LOG2CAP);
+        for (uint32_t t = 0; t < 128u; t++) {  // a table this crowded is handed to the HBM path
+            uint32_t k = __hip_atomic_load(&keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (k == KH_EMPTY_PID) {
+                const uint32_t old = atomicCAS(&keys[h], KH_EMPTY_PID, pid);
+                // the distinct hits are counted as they come (at most 8192 bumps of one LDS word per query): the attempt is
+                // given up the moment the table is three quarters full, not after every further id has walked a full table
+                if (old == KH_EMPTY_PID) { k = pid; if (atomicAdd(nd, 1u) >= LIMIT) return false; }
+                else k = old;
+            }
+            if (k == pid) {
+                atomicAdd(&val[h], n);  // counts stay below 65 536: one per position of the query at most
+                uint32_t old = __hip_atomic_load(&val[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                while (pos < (old >> 16)) {
+                    const uint32_t seen = atomicCAS(&val[h], old, (old & 0xFFFFu) | (pos << 16));
+                    if (seen == old) break;
+                    old = seen;
+                }
+                return true;
+            }
+            h = (h + 1u) & (CAP - 1u);
+        }
+        return false;
+    }
+    __device__ __forceinline__ bool over_limit() const { return false; }
+};
+
 // A slot is 16 bytes {protein id, count, lowest position, -}: one memory line per table add.  As three arrays an add
 // touched three random lines of a table that is megabytes large, and the tier ran at the speed of those line fills and
 // write-backs (14 ms per batch on the skewed database, 53 GB of traffic).
@@ -491,7 +529,7 @@ __device__ __forceinline__ bool add_runs(const Table &tab, uint32_t x, uint32_t 
 // by binary search in the prefix of their lengths -- a thread per id.  One wave walking a 9 000-protein list 64 ids at a
 // time, for each of the 21 positions of a shared motif, is 3 000 dependent round trips while fifteen waves wait.
 #define LONG_LIST 8u
-#define LONG_SINK_CAP 2048u
+#define LONG_SINK_CAP 1024u
 struct LongSink {
     uint32_t n;
     uint32_t off[LONG_SINK_CAP], pos[LONG_SINK_CAP], cnt[LONG_SINK_CAP];  // cnt becomes the exclusive prefix
@@ -675,6 +713,7 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
     __shared__ uint32_t s_pref[WAVES][NWIN * 64];
     __shared__ unsigned long long s_post, s_off, s_base;
     __shared__ LongSink s_long;
+    __shared__ uint32_t b_keys[BigLdsTable::CAP], b_val[BigLdsTable::CAP];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint32_t n_items = *p.list_count < p.list_cap ? *p.list_count : p.list_cap;
@@ -682,6 +721,42 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
     PostCtr pc;
     NullTable nt;
     nt.nd = &s_nd;
+    // the long postings lists a sweep set aside, expanded by all threads into `tab`
+    auto expand_long = [&](const auto &tab) {
+        const uint32_t nl = s_long.n < LONG_SINK_CAP ? s_long.n : LONG_SINK_CAP;
+        if (wv == 0 && nl) {  // lengths -> exclusive prefix (16 entries per lane)
+            constexpr uint32_t PER = LONG_SINK_CAP / 64;
+            uint32_t sum = 0;
+            for (uint32_t i = 0; i < PER; i++) { const uint32_t e = lane * PER + i; sum += e < nl ? s_long.cnt[e] : 0u; }
+            uint32_t inc = sum;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = __shfl_up(inc, o, 64);
+                if ((int)lane >= o) inc += t;
+            }
+            uint32_t run = inc - sum;
+            for (uint32_t i = 0; i < PER; i++) {
+                const uint32_t e = lane * PER + i;
+                if (e < nl) { const uint32_t c = s_long.cnt[e]; s_long.cnt[e] = run; run += c; }
+            }
+            if (lane == 63) s_long.total = inc;
+        }
+        __syncthreads();
+        uint32_t nnew = 0;
+        bool ok = true;
+        const uint32_t total = nl ? s_long.total : 0u;
+        for (uint32_t t = tid; t < total; t += 64 * WAVES) {
+            if (s_fail) break;  // (the table gave up: no point in the rest)
+            uint32_t e = 0;  // largest e with prefix[e] <= t
+#pragma unroll
+            for (uint32_t sft = LONG_SINK_CAP / 2; sft > 0; sft >>= 1)
+                if (e + sft < nl && s_long.cnt[e + sft] <= t) e += sft;
+            if (!tab.add_n(p.arena[(uint64_t)s_long.off[e] * 4 + 1 + (t - s_long.cnt[e])], s_long.pos[e], 1u, nnew)) { ok = false; s_fail = 1; }
+        }
+        const uint32_t wn = wave_total(nnew);
+        if (lane == 0 && wn) atomicAdd(&s_nd, wn);
+        if (!ok) s_fail = 1;
+    };
 
     for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
         const WorkItem wi = p.list[item];
@@ -699,6 +774,53 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
             if (lane == 0 && wp) atomicAdd(&s_post, wp);
         }
         __syncthreads();
+        // ---- first attempt: the whole query in the big LDS table
+        if (size < 65535) {
+            BigLdsTable bt;
+            bt.keys = b_keys; bt.val = b_val; bt.nd = &s_nd;
+            for (uint32_t i = tid; i < BigLdsTable::CAP; i += 64 * WAVES) { b_keys[i] = KH_EMPTY_PID; b_val[i] = 0xFFFF0000u; }
+            __syncthreads();
+            pc.clear();
+            for (int32_t r0 = 0; r0 < size && !s_fail; r0 += 64 * WAVES * NWIN) {
+                const bool ok = count_windows<BigLdsTable, NWIN, false>(p, vals, size, r0 + 64 * (int32_t)wv, 64 * WAVES, bt, pc,
+                                                                       s_pref[wv], &s_long);
+                if (!ok) s_fail = 1;
+            }
+            __syncthreads();
+            expand_long(bt);
+            __syncthreads();
+            const uint32_t total = s_nd;
+            const bool fits = s_fail == 0u && total <= BigLdsTable::LIMIT;
+            __syncthreads();
+            if (fits) {
+                if (tid == 0) s_base = total ? tail_alloc(p, total) : 0ull;
+                __syncthreads();
+                const unsigned long long base = s_base;
+                if (base != ~0ull && total > 0) {
+                    for (uint32_t i0 = wv * 64u; i0 < BigLdsTable::CAP; i0 += 64 * WAVES) {
+                        const uint32_t k = b_keys[i0 + lane];
+                        const bool has = k != KH_EMPTY_PID;
+                        const unsigned long long bm = __ballot(has);
+                        uint32_t wbase = 0;
+                        if (lane == 0 && bm) wbase = atomicAdd(&s_cursor, (uint32_t)__popcll(bm));
+                        wbase = __shfl(wbase, 0, 64);
+                        if (has) {
+                            const uint32_t idx = wbase + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull));
+                            const uint32_t v = b_val[i0 + lane];
+                            p.hit_pid[base + idx] = k;
+                            p.hit_km[base + idx] = v & 0xFFFFu;
+                            p.hit_fp[base + idx] = v >> 16;
+                        }
+                    }
+                    if (wv == 0) tot_hits += total;
+                }
+                if (tid == 0) { p.q_cnt[q] = (base != ~0ull) ? total : 0u; p.hit_off[q] = base == ~0ull ? 0 : base; }
+                __syncthreads();
+                continue;
+            }
+            if (tid == 0) { s_nd = 0; s_fail = 0; s_cursor = 0; s_long.n = 0; }  // too many distinct hits: the HBM table
+            __syncthreads();
+        }
         unsigned long long bound = s_post;
         if (bound > p.n_proteins) bound = p.n_proteins;
         uint32_t log2cap = 10;
@@ -732,40 +854,7 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
             if (!ok) s_fail = 1;
         }
         __syncthreads();
-        {   // the long postings lists the sweep set aside
-            const uint32_t nl = s_long.n < LONG_SINK_CAP ? s_long.n : LONG_SINK_CAP;
-            if (wv == 0 && nl) {  // lengths -> exclusive prefix (32 entries per lane)
-                constexpr uint32_t PER = LONG_SINK_CAP / 64;
-                uint32_t sum = 0;
-                for (uint32_t i = 0; i < PER; i++) { const uint32_t e = lane * PER + i; sum += e < nl ? s_long.cnt[e] : 0u; }
-                uint32_t inc = sum;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const uint32_t t = __shfl_up(inc, o, 64);
-                    if ((int)lane >= o) inc += t;
-                }
-                uint32_t run = inc - sum;
-                for (uint32_t i = 0; i < PER; i++) {
-                    const uint32_t e = lane * PER + i;
-                    if (e < nl) { const uint32_t c = s_long.cnt[e]; s_long.cnt[e] = run; run += c; }
-                }
-                if (lane == 63) s_long.total = inc;
-            }
-            __syncthreads();
-            uint32_t nnew = 0;
-            bool ok = true;
-            const uint32_t total = nl ? s_long.total : 0u;
-            for (uint32_t t = tid; t < total; t += 64 * WAVES) {
-                uint32_t e = 0;  // largest e with prefix[e] <= t
-#pragma unroll
-                for (uint32_t sft = LONG_SINK_CAP / 2; sft > 0; sft >>= 1)
-                    if (e + sft < nl && s_long.cnt[e + sft] <= t) e += sft;
-                ok = gt.add_n(p.arena[(uint64_t)s_long.off[e] * 4 + 1 + (t - s_long.cnt[e])], s_long.pos[e], 1u, nnew) && ok;
-            }
-            const uint32_t wn = wave_total(nnew);
-            if (lane == 0 && wn) atomicAdd(&s_nd, wn);
-            if (!ok) s_fail = 1;
-        }
+        expand_long(gt);
         __syncthreads();
         // lookups, postings and queries were already counted by the group kernel
         const uint32_t total = s_nd;

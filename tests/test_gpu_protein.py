@@ -173,15 +173,16 @@ def test_tier_escalation_is_exact(klib, oracle, gpu_device):
     alpha = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
     core = bytes(alpha[rng.integers(0, 20, 40)])
     long_q = bytes(alpha[rng.integers(0, 20, 300)]) + core + bytes(alpha[rng.integers(0, 20, 400)])
-    # 5000 proteins share the core with ragged ends -> 5000 distinct hits for a query holding the core
-    db = [bytes(alpha[rng.integers(0, 20, 8)]) + core[(i % 5):] + bytes(alpha[rng.integers(0, 20, 8)]) for i in range(5000)]
-    ids = (np.arange(5000, dtype=np.uint32) * 3 + 1)
+    # 9000 proteins share the core with ragged ends -> 9000 distinct hits for a query holding the core: past the group
+    # tables (4096 slots) and past the G tier's LDS table (6144 distinct hits), so the HBM table is what counts them
+    db = [bytes(alpha[rng.integers(0, 20, 8)]) + core[(i % 5):] + bytes(alpha[rng.integers(0, 20, 8)]) for i in range(9000)]
+    ids = (np.arange(9000, dtype=np.uint32) * 3 + 1)
     img = api.Image.from_proteins(db, ids=ids)
     ix = api.Index.from_image(img, gpu_device)
     oix = oracle.Index.from_proteins(db, ids=ids)
     seqs = [core, long_q, db[7], core[:20], b"ACDEFGHIKLMNPQRSTVWY"]
     exp = _oracle_hits(oix, oracle, seqs)
-    assert len(exp[0][0]) == 5000
+    assert len(exp[0][0]) == 9000
     for opts in (dict(), dict(compact=True), dict(g_tier_slots=1 << 20)):
         hits, first, c = _device_search(ix, seqs, **opts)
         for i, (h, f) in enumerate(exp):
