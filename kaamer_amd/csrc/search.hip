@@ -100,7 +100,7 @@ enum { LIST_S = 0, LIST_L, LIST_SO, LIST_G, N_LISTS };
 // small per-batch device state after the list counters (all zeroed by the finalize step)
 enum { SLOT_QUEUE_HEAD = N_LISTS, SLOT_STATUS = N_LISTS + 1, SLOT_GROUP_QUEUE = N_LISTS + 2, SLOT_GROUP_QUEUE_POS = N_LISTS + 3,
        SLOT_N_LONG = N_LISTS + 4, SLOT_TILES_DONE = N_LISTS + 5, SLOT_TR_TICKET = N_LISTS + 6,
-       SLOT_QUEUE_SUB = N_LISTS + 7 /* 8 words */, N_SMALL_SLOTS = N_LISTS + 15 };
+       SLOT_QUEUE_SUB = N_LISTS + 7 /* 8 words */, SLOT_G_TICKET = N_LISTS + 15, N_SMALL_SLOTS = N_LISTS + 16 };
 // one entry: everything a tier needs to start on a query, in one 16-byte load
 struct alignas(16) WorkItem {
     uint32_t q;
@@ -758,13 +758,20 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
         if (!ok) s_fail = 1;
     };
 
-    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
+    // items are handed out by ticket (after the first one): a query here costs anything from microseconds to
+    // milliseconds, and two expensive ones on the same workgroup's static share were the tier's tail
+    __shared__ uint32_t s_item;
+    for (uint32_t item = blockIdx.x; item < n_items;) {
         const WorkItem wi = p.list[item];
         const uint32_t q = wi.q;
         const int32_t size = wi.size;
         const uint32_t *vals = p.vals + wi.aa_off;
-        if (tid == 0) { s_nd = 0; s_fail = 0; s_post = 0; s_cursor = 0; s_long.n = 0; }
+        if (tid == 0) {
+            s_nd = 0; s_fail = 0; s_post = 0; s_cursor = 0; s_long.n = 0;
+            s_item = atomicAdd(p.queue_head + (SLOT_G_TICKET - SLOT_QUEUE_HEAD), 1u) + gridDim.x;  // the next item of this workgroup
+        }
         __syncthreads();
+        item = s_item;
         // pass 1: exact number of postings (an upper bound of the distinct proteins)
         pc.clear();
         for (int32_t r0 = 0; r0 < size; r0 += 64 * WAVES * NWIN)
