@@ -112,7 +112,7 @@ struct alignas(16) WorkItem {
 #define MAX_TIMED_CALLS 1024u
 #define L_WAVES 8
 #define L_LOG2CAP 12
-#define G_WAVES 4
+#define G_WAVES 8
 #ifndef S_MIN_WAVES
 #define S_MIN_WAVES 1
 #endif
