@@ -717,6 +717,10 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
     const uint32_t n_items = *p.list_count < p.list_cap ? *p.list_count : p.list_cap;
+    // the grid is sized for a batch full of overflowing queries; most batches have none, and the workgroups beyond the
+    // items (all but one when there are none) leave at once -- they take no part in the completion count either
+    const uint32_t n_part = n_items < gridDim.x ? (n_items ? n_items : 1u) : gridDim.x;
+    if (blockIdx.x >= n_part) return;
     unsigned long long tot_hits = 0;
     PostCtr pc;
     NullTable nt;
@@ -768,7 +772,7 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
         const uint32_t *vals = p.vals + wi.aa_off;
         if (tid == 0) {
             s_nd = 0; s_fail = 0; s_post = 0; s_cursor = 0; s_long.n = 0;
-            s_item = atomicAdd(p.queue_head + (SLOT_G_TICKET - SLOT_QUEUE_HEAD), 1u) + gridDim.x;  // the next item of this workgroup
+            s_item = atomicAdd(p.queue_head + (SLOT_G_TICKET - SLOT_QUEUE_HEAD), 1u) + n_part;  // the next item of this workgroup
         }
         __syncthreads();
         item = s_item;
@@ -915,7 +919,7 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
         // two levels: 512 workgroups bumping ONE word serialise at ~90 per microsecond (6 us of a 0.2 ms batch);
         // eight sub-counters (workgroup index mod 8), and the last arrival of each bumps the top one
         if (tid == 0) {
-            const uint32_t sub = blockIdx.x & 7u, n_sub = (gridDim.x - sub + 7u) >> 3, n_top = gridDim.x < 8u ? gridDim.x : 8u;
+            const uint32_t sub = blockIdx.x & 7u, n_sub = (n_part - sub + 7u) >> 3, n_top = n_part < 8u ? n_part : 8u;
             s_last = 0;
             if (atomicAdd(p.queue_head + (SLOT_QUEUE_SUB - SLOT_QUEUE_HEAD) + sub, 1u) == n_sub - 1u)
                 s_last = atomicAdd(p.queue_head, 1u) == n_top - 1u;
