@@ -346,7 +346,7 @@ def main():
     #                  (1 B per nucleotide + 8 B of offsets per read in; 1 B per ORF residue + 40 B of meta per ORF out) and
     #                  the ORF prep (40 B meta in, 32 B descriptor / table size / hit offset / count out per ORF)
     c = avg
-    hit_b = 12 if (nucl or sharded_mode) else 8
+    hit_b = 12 if nucl else 8
     n_pos = c["n_in"] if nucl else float(np.mean([len(q[0]) for q in batches]))  # positions kernel P walks
     probe_bytes = n_pos + n_pos / 8 + BUCKET_BYTES * c["n_probe"] + 4 * n_pos
     count_bytes = 4 * n_pos + 4 * (c["n_lists"] + c["n_list_ids"]) + 36 * c["n_queries"] + hit_b * c["n_hits"]

@@ -344,6 +344,7 @@ struct CountParams {
     unsigned long long *pos_bits;
     // merge of partial hit lists (count_group_kernel MODE 2)
     const uint32_t *m_pid, *m_km, *m_fp;
+    uint32_t merge_fp;  // 0: the partial entries carry no first positions
     // tier input / overflow output lists
     const WorkItem *list;
     const uint32_t *list_count;
@@ -1265,9 +1266,11 @@ static void launch_group_positions(const CountParams &p, int grid, hipStream_t s
 {
     hipLaunchKernelGGL((count_group_kernel<false, 1>), dim3(grid), dim3(64 * GRP_WAVES), 0, s, p);
 }
-static void launch_group_merge(const CountParams &p, int grid, hipStream_t s)
+static void launch_group_merge(const CountParams &p, int grid, bool firstpos, hipStream_t s)
 {
-    hipLaunchKernelGGL((count_group_kernel<true, 2>), dim3(grid), dim3(64 * GRP_WAVES), 0, s, p);
+    // without first positions the merge tables need no third array: three workgroups per CU instead of two
+    if (firstpos) hipLaunchKernelGGL((count_group_kernel<true, 2>), dim3(grid), dim3(64 * GRP_WAVES), 0, s, p);
+    else hipLaunchKernelGGL((count_group_kernel<false, 2>), dim3(grid), dim3(64 * GRP_WAVES), 0, s, p);
 }
 
 extern "C" {
@@ -1825,7 +1828,7 @@ static int merge_device_impl(kaamer_workspace *ws, const uint64_t *d_ent_off, co
     p.d_nq = ws->d_nq;
     p.last_group_pass = 1u;
     p.group_queue = ws->d_list_counts + SLOT_GROUP_QUEUE;
-    p.m_pid = d_pid; p.m_km = d_km; p.m_fp = d_fp;
+    p.m_pid = d_pid; p.m_km = d_km; p.m_fp = d_fp; p.merge_fp = ws->firstpos ? 1u : 0u;
     p.list_cap = ws->q_cap;
     p.hit_off = ws->d_hit_off;
     p.q_cnt = ws->d_q_cnt;
@@ -1842,7 +1845,7 @@ static int merge_device_impl(kaamer_workspace *ws, const uint64_t *d_ent_off, co
     {
         uint64_t gb = ((uint64_t)GRP_MIN_TABLE * nq_bound + 3 * n_entries) / GRP_BUDGET + 1;
         if (gb > (uint64_t)ws->grp_grid) gb = ws->grp_grid;
-        launch_group_merge(p, (int)gb, s);
+        launch_group_merge(p, (int)gb, ws->firstpos, s);
     }
     CountParams pg = p;
     pg.list = list_ptr(LIST_G); pg.list_count = ws->d_list_counts + LIST_G;
@@ -1910,6 +1913,7 @@ int kaamer_exchange_pack(kaamer_workspace *ws, const kaamer_exchange_layout *L, 
     x.pid = ws->compact ? ws->d_c_pid : ws->d_hit_pid;
     x.km = ws->compact ? ws->d_c_km : ws->d_hit_km;
     x.fp = ws->compact ? ws->d_c_fp : ws->d_hit_fp;
+    x.with_fp = ws->firstpos ? 1u : 0u;
     x.send = d_send;
     x.dst_off = ws->d_x_dst_off;
     hipStream_t s = (hipStream_t)stream;
@@ -1960,6 +1964,7 @@ int kaamer_exchange_merge(kaamer_workspace *ws, const kaamer_exchange_layout *L,
     x.ent_off = ws->d_x_ent_off;
     x.d_nq_owned = ws->d_x_nq_owned;
     x.m_pid = ws->d_x_pid; x.m_km = ws->d_x_km; x.m_fp = ws->d_x_fp;
+    x.with_fp = ws->firstpos ? 1u : 0u;
     x.m_cap = m_cap;
     x.status = ws->d_list_counts + SLOT_STATUS;
     hipLaunchKernelGGL(x_unpack_scan_kernel, dim3(L->world + 1), dim3(X_BLOCK), 0, s, x);

@@ -120,16 +120,22 @@ class ShardedSearcher:
     the owner's post-steps use its own ORFs: orf_source)."""
 
     def __init__(self, index, rank, world, max_seq_bytes, max_seqs, seq_type=abi.PROTEIN, max_entries_per_peer=1 << 20,
-                 group=None, max_hits=0, g_tier_slots=0):
+                 group=None, max_hits=0, g_tier_slots=0, first_pos=None):
+        """first_pos: carry the lowest matching position of every hit through the exchange.  Default: as the reference
+        fills PositionHits (search.go:416) -- nucleotide / reads input yes (SetBestStartCodon reads it), protein input no
+        (a third less to pack, send, unpack and merge)."""
         self.index, self.rank, self.world, self.group = index, rank, world, group
         self.nucl = seq_type in (abi.READS, abi.NUCLEOTIDE)
-        self.ws = api.Workspace(index, max_seq_bytes, max_seqs, seq_type=seq_type, first_pos=1, max_hits=max_hits,
+        if first_pos is None:
+            first_pos = self.nucl
+        fp = 1 if first_pos else 2
+        self.ws = api.Workspace(index, max_seq_bytes, max_seqs, seq_type=seq_type, first_pos=fp, max_hits=max_hits,
                                 g_tier_slots=g_tier_slots)
         self.layout = abi.ExchangeLayout()
         abi.check(abi.lib().kaamer_exchange_layout_init(world, rank, self.ws.query_capacity, max_entries_per_peer,
                                                         C.byref(self.layout)))
         L = self.layout
-        self.mws = api.Workspace(index, 64, L.q_cap, max_queries=L.q_cap, first_pos=1, max_hits=world * L.e_cap,
+        self.mws = api.Workspace(index, 64, L.q_cap, max_queries=L.q_cap, first_pos=fp, max_hits=world * L.e_cap,
                                  g_tier_slots=g_tier_slots)
         n = world * int(L.block_words)
         self.send = torch.empty(n, dtype=torch.int32, device="cuda")

@@ -211,11 +211,12 @@ def _oracle_report(oracle, oix, orf, reads):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("reads", [False, True])
-def test_sharded_through_the_c_abi(klib, oracle, gpu_device, reads):
+@pytest.mark.parametrize("reads,first_pos", [(False, True), (False, False), (True, True)])
+def test_sharded_through_the_c_abi(klib, oracle, gpu_device, reads, first_pos):
     """W = 2 shards on one GPU, every step through the C ABI: search each shard, kaamer_exchange_pack, route the
     blocks as the all-to-all would, kaamer_exchange_merge on each owner, kaamer_topn_device with orf_source --
-    for protein queries and for reads (every rank translates; SetBestStartCodon on the owner).  Also W = 1
+    for protein queries (with first positions, and without: the protein default, where the exchange leaves that
+    third of the entries alone) and for reads (every rank translates; SetBestStartCodon on the owner).  Also W = 1
     (send buffer = receive buffer), which must reproduce the unsharded results."""
     import ctypes as C
     import torch
@@ -242,7 +243,8 @@ def test_sharded_through_the_c_abi(klib, oracle, gpu_device, reads):
         ranks = []
         for r in range(world):
             ix = api.Index.from_image(api.Image.from_proteins(packed=db, shard=r, n_shards=world), gpu_device)
-            ranks.append((ix, sharded.ShardedSearcher(ix, r, world, len(buf), n_seqs, seq_type=seq_type, max_entries_per_peer=1 << 16)))
+            ranks.append((ix, sharded.ShardedSearcher(ix, r, world, len(buf), n_seqs, seq_type=seq_type, max_entries_per_peer=1 << 16,
+                                                      first_pos=first_pos)))
         # search + pack on every "rank" (the searcher's own step() does the same, then the collective)
         for ix, ss in ranks:
             ss.ws.search_device(d_buf.data_ptr(), d_off.data_ptr(), n_seqs, len(buf), stream=st.cuda_stream)
@@ -269,7 +271,10 @@ def test_sharded_through_the_c_abi(klib, oracle, gpu_device, reads):
             for j, qi in enumerate(owned):
                 a, b = int(hit_off[j]), int(hit_off[j]) + int(hit_cnt[j])
                 got = {int(x): (int(y), int(z)) for x, y, z in zip(pid[a:b], km[a:b], fp[a:b])}
-                assert got == exp[qi][0], (world, d, qi)
+                if first_pos:
+                    assert got == exp[qi][0], (world, d, qi)
+                else:  # no first positions asked for: the field reads as zeros
+                    assert got == {k_: (v_[0], 0) for k_, v_ in exp[qi][0].items()}, (world, d, qi)
                 k = len(exp[qi][1])
                 assert int(tc[j]) == k, (world, d, qi)
                 assert list(zip(tp[j, :k].tolist(), tk[j, :k].tolist())) == exp[qi][1], (world, d, qi)
@@ -277,7 +282,7 @@ def test_sharded_through_the_c_abi(klib, oracle, gpu_device, reads):
         assert n_checked > 500
     # a block too small for the partial lists is reported, never a partial result
     ix, ss = ranks[0]
-    small = sharded.ShardedSearcher(ix, 0, 2, len(buf), n_seqs, seq_type=seq_type, max_entries_per_peer=64)
+    small = sharded.ShardedSearcher(ix, 0, 2, len(buf), n_seqs, seq_type=seq_type, max_entries_per_peer=64, first_pos=first_pos)
     small.ws.search_device(d_buf.data_ptr(), d_off.data_ptr(), n_seqs, len(buf), stream=st.cuda_stream)
     small.ws.exchange_pack(small.layout, small.send.data_ptr(), st.cuda_stream)
     small.mws.exchange_merge(small.layout, small.send.data_ptr(), st.cuda_stream)
