@@ -289,6 +289,17 @@ def test_sharded_through_the_c_abi(klib, oracle, gpu_device, reads, first_pos):
     with pytest.raises(abi.KaamerError) as e:
         small.mws.finish(st.cuda_stream)
     assert e.value.code == abi.E_CAPACITY
+    if not first_pos:
+        # blocks packed without first positions handed to an owner that wants them: reported, not merged as zeros
+        ix, ss = ranks[0]
+        want = sharded.ShardedSearcher(ix, 0, 1, len(buf), n_seqs, seq_type=seq_type, max_entries_per_peer=1 << 16, first_pos=True)
+        ss1 = sharded.ShardedSearcher(ix, 0, 1, len(buf), n_seqs, seq_type=seq_type, max_entries_per_peer=1 << 16, first_pos=False)
+        ss1.ws.search_device(d_buf.data_ptr(), d_off.data_ptr(), n_seqs, len(buf), stream=st.cuda_stream)
+        ss1.ws.exchange_pack(ss1.layout, ss1.send.data_ptr(), st.cuda_stream)
+        ss1.ws.finish(st.cuda_stream)
+        want.mws.exchange_merge(want.layout, ss1.send.data_ptr(), st.cuda_stream)
+        with pytest.raises(abi.KaamerError):
+            want.mws.finish(st.cuda_stream)
 
 
 @pytest.mark.gpu
