@@ -367,7 +367,10 @@ void kaamer_batch_top_free(kaamer_batch_top *out);
 /*                      rank, q_stride = W)                                        */
 /* Block capacities are bounds like every workspace bound: exceeding them is      */
 /* reported as KAAMER_E_CAPACITY by kaamer_workspace_finish, never a partial       */
-/* result.                                                                         */
+/* result.  First positions travel only when the search workspace computes them    */
+/* (opts.first_pos = 1, or nucleotide / reads input); create the owner's merge      */
+/* workspace with the same explicit setting (1 or 2) -- an owner that wants them    */
+/* and receives blocks without them reports the same error.                         */
 /* ------------------------------------------------------------------------- */
 typedef struct {
     uint32_t world, rank;
