@@ -389,7 +389,10 @@ uint32_t kaamer_workspace_query_capacity(const kaamer_workspace *ws);
 int kaamer_exchange_pack(kaamer_workspace *search_ws, const kaamer_exchange_layout *layout,
                          uint32_t *d_send, void *stream);
 /* d_recv[world * block_words] (block s = what rank s sent to this rank) -> merged results in
- * `merge_ws` (max_queries >= layout->q_cap, max_hits >= world * layout->e_cap, first_pos = 1) */
+ * `merge_ws` (max_queries >= layout->q_cap, max_hits >= world * layout->e_cap, first_pos = 1 or 2: the same explicit
+ * setting as the search workspace).  Blocks whose headers do not describe ONE batch (ranks on different batches, a
+ * stale buffer), blocks that overflowed, and blocks of a sender whose own search failed all make the merge an error
+ * (KAAMER_E_CAPACITY at kaamer_workspace_finish): never a partial result. */
 int kaamer_exchange_merge(kaamer_workspace *merge_ws, const kaamer_exchange_layout *layout,
                           const uint32_t *d_recv, void *stream, kaamer_device_result *out);
 /* Grouped ncclSend / ncclRecv of world equal blocks on `stream` with the caller's ncclComm_t.

@@ -224,55 +224,69 @@ class TopResult:
         return pid, km
 
 
-class BatchResult:
-    """Host view of one kaamer_batch_out: the arrays are views of the C object's buffers (no copies), which
-    this object owns and frees with itself."""
+class _BatchOwner:
+    """frees one kaamer_batch_out when the last array that views its buffers is gone"""
 
     def __init__(self, out):
-        self._out = out
+        self.out = out
+
+    def __del__(self):
+        try:
+            if self.out is not None:
+                abi.lib().kaamer_batch_free(self.out)
+                self.out = None
+        except Exception:
+            pass
+
+
+def _owned_view(owner, ptr, n, dtype):
+    """numpy view of n items at `ptr` (a ctypes pointer) that keeps `owner` alive: the exporting ctypes array holds a
+    reference to it, and every array derived from the view holds the exporter"""
+    dtype = np.dtype(dtype)
+    if n == 0:
+        return np.zeros(0, dtype)
+    raw = (C.c_uint8 * (n * dtype.itemsize)).from_address(C.cast(ptr, C.c_void_p).value)
+    raw._owner = owner
+    return np.frombuffer(raw, dtype=dtype)
+
+
+class BatchResult:
+    """Host view of one kaamer_batch_out: the arrays are views of the C object's buffers (no copies).  The buffers
+    live as long as any of the arrays (or anything sliced from them) does: `ix.search(...).hit_pid` stays valid after
+    the BatchResult itself is gone."""
+
+    def __init__(self, out):
         o = out.contents
+        own = _BatchOwner(out)
         n = o.n_queries
         self.n_queries = n
-        view = np.ctypeslib.as_array
-        meta = view(C.cast(o.q, C.POINTER(C.c_uint8)), shape=(n * C.sizeof(abi.QueryMeta),)) if n else np.zeros(0, np.uint8)
-        self.meta = meta.view(np.dtype([("src_seq", "<u4"), ("size_in_kmer", "<i4"), ("start_position", "<i4"),
-                                        ("end_position", "<i4"), ("plus_strand", "<i4"), ("aa_len", "<u4"),
-                                        ("aa_off", "<u8"), ("sa_off", "<u4"), ("sa_len", "<u4")]))
-        self.hit_off = view(o.hit_off, shape=(n + 1,))
-        self.hit_cnt = view(o.hit_cnt, shape=(n,)) if n else np.zeros(0, np.uint32)
+        self.meta = _owned_view(own, o.q, n, META_DTYPE)
+        self.hit_off = _owned_view(own, o.hit_off, n + 1, np.uint64)
+        self.hit_cnt = _owned_view(own, o.hit_cnt, n, np.uint32)
         nh = int(self.hit_off[n])
-        z = np.zeros(0, np.uint32)
-        self.hit_pid = view(o.hit_pid, shape=(nh,)) if nh else z
-        self.hit_kmatch = view(o.hit_kmatch, shape=(nh,)) if nh else z
-        self.hit_first_pos = view(o.hit_first_pos, shape=(nh,)) if nh else z
+        self.hit_pid = _owned_view(own, o.hit_pid, nh, np.uint32)
+        self.hit_kmatch = _owned_view(own, o.hit_kmatch, nh, np.uint32)
+        self.hit_first_pos = _owned_view(own, o.hit_first_pos, nh, np.uint32)
         self.counters = o.counters.as_dict()
         self.pos_off = self.pos_bits = None
         if bool(o.pos_off) and bool(o.pos_bits):
-            self.pos_off = view(o.pos_off, shape=(nh,)) if nh else np.zeros(0, np.uint64)
+            self.pos_off = _owned_view(own, o.pos_off, nh, np.uint64)
             nw = 0
             if nh:  # words in use = end of the last bitmap
                 has = self.hit_cnt > 0
                 last = (self.hit_off[:n][has] + self.hit_cnt[has].astype(np.uint64) - np.uint64(1)).astype(np.int64)
                 words = (self.meta["size_in_kmer"][has].astype(np.int64) + 63) // 64
                 nw = int((self.pos_off[last].astype(np.int64) + words).max())
-            self.pos_bits = view(o.pos_bits, shape=(nw,)) if nw else np.zeros(0, np.uint64)
+            self.pos_bits = _owned_view(own, o.pos_bits, nw, np.uint64)
         aa_len = int((self.meta["aa_off"] + self.meta["aa_len"]).max()) if n and bool(o.orf_aa) else 0
-        self.orf_aa = view(o.orf_aa, shape=(aa_len,)) if aa_len else np.zeros(0, np.uint8)
+        self.orf_aa = _owned_view(own, o.orf_aa, aa_len, np.uint8)
         sa_len = int((self.meta["sa_off"] + self.meta["sa_len"]).max()) if n and bool(o.starts_alt) else 0
-        self.starts_alt = view(o.starts_alt, shape=(sa_len,)) if sa_len else np.zeros(0, np.int32)
+        self.starts_alt = _owned_view(own, o.starts_alt, sa_len, np.int32)
 
     def close(self):
-        if self._out is not None:
-            for k in ("meta", "hit_off", "hit_cnt", "hit_pid", "hit_kmatch", "hit_first_pos", "pos_off", "pos_bits", "orf_aa", "starts_alt"):
-                setattr(self, k, None)  # the views die with the buffers
-            abi.lib().kaamer_batch_free(self._out)
-            self._out = None
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
+        """drops this object's views (the buffers go when no other array views them)"""
+        for k in ("meta", "hit_off", "hit_cnt", "hit_pid", "hit_kmatch", "hit_first_pos", "pos_off", "pos_bits", "orf_aa", "starts_alt"):
+            setattr(self, k, None)
 
     def span(self, q):
         """[first, last+1) of query q's hits in the hit arrays"""

@@ -90,7 +90,7 @@ struct kaamer_index {
 };
 
 enum { ST_POOL_FULL = 1u, ST_LIST_FULL = 2u, ST_QUERY_CAP = 4u, ST_AA_CAP = 8u, ST_G_ARENA_FULL = 16u, ST_G_TABLE_FULL = 32u,
-       ST_POS_UNSUPPORTED = 64u, ST_POS_CAP = 128u, ST_CHAIN_TIMEOUT = 256u, ST_EXCHANGE_CAP = 512u };
+       ST_POS_UNSUPPORTED = 64u, ST_POS_CAP = 128u, ST_CHAIN_TIMEOUT = 256u, ST_EXCHANGE_CAP = 512u, ST_PEER_FAILED = 1024u };
 enum { CTR_IN = 0, CTR_QUERIES, CTR_LOOKUP, CTR_PROBE, CTR_FOUND, CTR_POST, CTR_HITS, CTR_OVERFLOW, CTR_LISTS, CTR_LIST_IDS, CTR_N };
 static_assert(sizeof(kaamer_counters) == CTR_N * 8, "counter layout");
 #define CTR_REPLICAS 64
@@ -530,7 +530,8 @@ __device__ __forceinline__ bool add_runs(const Table &tab, uint32_t x, uint32_t 
 // by binary search in the prefix of their lengths -- a thread per id.  One wave walking a 9 000-protein list 64 ids at a
 // time, for each of the 21 positions of a shared motif, is 3 000 dependent round trips while fifteen waves wait.
 #define LONG_LIST 8u
-#define LONG_SINK_CAP 1024u
+#define LONG_SINK_CAP 960u   /* 15 entries per lane; with 1024 the kernel's LDS was 56 bytes over half a CU's: one workgroup per CU */
+#define LONG_SINK_LIFT 512u  /* first step of the binary lifting over the prefix: the largest power of two below the capacity */
 struct LongSink {
     uint32_t n;
     uint32_t off[LONG_SINK_CAP], pos[LONG_SINK_CAP], cnt[LONG_SINK_CAP];  // cnt becomes the exclusive prefix
@@ -754,7 +755,7 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
             if (s_fail) break;  // (the table gave up: no point in the rest)
             uint32_t e = 0;  // largest e with prefix[e] <= t
 #pragma unroll
-            for (uint32_t sft = LONG_SINK_CAP / 2; sft > 0; sft >>= 1)
+            for (uint32_t sft = LONG_SINK_LIFT; sft > 0; sft >>= 1)
                 if (e + sft < nl && s_long.cnt[e + sft] <= t) e += sft;
             if (!tab.add_n(p.arena[(uint64_t)s_long.off[e] * 4 + 1 + (t - s_long.cnt[e])], s_long.pos[e], 1u, nnew)) { ok = false; s_fail = 1; }
         }
@@ -852,9 +853,12 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
         }
         GlobalTable gt;
         gt.slots = p.g_keys + 4ull * off; gt.nd = &s_nd; gt.log2cap = log2cap;
-        // The table is only ever touched with device-scope atomics (initialisation included), which
-        // are performed past the L2: no agent-scope fence -- a full L2 write-back on this part -- is
-        // needed between the phases, a workgroup barrier (which drains vmcnt) is enough.
+        // The table belongs to this workgroup alone (g_cursor never hands out a region twice within one launch) and is
+        // touched with plain 16-byte initialisation stores, workgroup-scope atomics and, at the end, plain read-out
+        // loads.  Nothing loads from it before the read-out, so no stale line can sit in the L1 (write-through, holds
+        // no line of the table); the atomics are performed in the XCD's L2, where the initialisation stores went.  A
+        // workgroup barrier (which drains vmcnt) between the phases is enough: no agent-scope fence -- a full L2
+        // write-back on this part.
         for (unsigned long long i = tid; i < cap; i += 64 * WAVES)
             reinterpret_cast<uint4 *>(gt.slots)[i] = make_uint4(KH_EMPTY_PID, 0u, 0xFFFFFFFFu, 0u);
         __syncthreads();
@@ -1405,7 +1409,11 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     ws->grp_grid = ws->n_cu * grp_per_cu;
     // the G tier is rare on a database like DB-SP, but with a skewed database 15 % of the queries overflow their LDS
     // table: enough workgroups to keep the memory system busy (the last one to finish also finalizes the batch)
-    ws->g_grid = ws->n_cu * 2;
+    {
+        int g_per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&g_per_cu, count_global_kernel, 64 * G_WAVES, 0) != hipSuccess || g_per_cu < 1) g_per_cu = 1;
+        ws->g_grid = ws->n_cu * (g_per_cu > 2 ? 2 : g_per_cu);
+    }
     ws->p_grid = ws->n_cu * p_per_cu;
     // a table has at most max(64, 3 x SizeInKmer) slots
     {
@@ -1908,6 +1916,7 @@ int kaamer_exchange_pack(kaamer_workspace *ws, const kaamer_exchange_layout *L, 
     XParams x;
     x_fill(x, L);
     x.d_nq = ws->d_nq;
+    x.src_status = ws->d_status_out;  // written by the search's finalize step, earlier on this stream
     x.hit_off = ws->compact ? ws->d_csr_off : ws->d_hit_off;
     x.hit_cnt = ws->d_q_cnt;
     x.pid = ws->compact ? ws->d_c_pid : ws->d_hit_pid;
@@ -2045,6 +2054,7 @@ int kaamer_topn_device(kaamer_workspace *ws, const kaamer_topn_opts *opts, void 
     memset(&p, 0, sizeof p);
     p.d_nq = ws->d_nq;
     p.q = src->d_q;
+    p.src_nq = src->d_nq;
     p.q_first = opts->orf_source ? opts->q_first : 0u;
     p.q_stride = opts->orf_source ? (opts->q_stride ? opts->q_stride : 1u) : 1u;
     p.size_in = opts->d_size_in_kmer;
@@ -2090,7 +2100,8 @@ int kaamer_workspace_finish(kaamer_workspace *ws, void *stream, kaamer_counters 
     if (status & ST_CHAIN_TIMEOUT) return kaamer_fail(KAAMER_E_HIP, "table layout: a tile never published its total");
     if (status & (ST_QUERY_CAP | ST_AA_CAP))
         return kaamer_fail(KAAMER_E_CAPACITY, "more ORFs than the workspace holds: raise workspace max_queries (now %u)", ws->q_cap);
-    if (status & ST_EXCHANGE_CAP) return kaamer_fail(KAAMER_E_CAPACITY, "exchange block capacity exceeded: raise max_entries_per_peer / max_queries of the exchange layout");
+    if (status & ST_EXCHANGE_CAP) return kaamer_fail(KAAMER_E_CAPACITY, "exchange block capacity exceeded (or the blocks do not describe one batch): raise max_entries_per_peer / max_queries of the exchange layout");
+    if (status & ST_PEER_FAILED) return kaamer_fail(KAAMER_E_CAPACITY, "a peer's search of this batch exceeded one of its workspace bounds: nothing was merged (that rank's kaamer_workspace_finish says which bound)");
     if (status & ST_POS_CAP) return kaamer_fail(KAAMER_E_CAPACITY, "position bitmaps exceed the workspace: raise max_pos_words (now %llu)", (unsigned long long)ws->bits_cap);
     if (status & ST_G_ARENA_FULL)
         return kaamer_fail(KAAMER_E_CAPACITY, "global counting arena exhausted: raise workspace g_tier_slots (now %llu)", (unsigned long long)ws->g_slots);

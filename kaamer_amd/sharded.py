@@ -6,95 +6,27 @@ keys they do not own), which yields partial hit lists `(protein id, partial Kmat
 position)` per query.  Query q is owned by rank `q % world`: one all-to-all (RCCL over
 xGMI: every rank talks to every other rank at once, all seven links busy — not a ring)
 moves each partial list to its owner, and the owner merges them on the device
-(`kaamer_merge_device`: integer sums, so the result is bit-identical to the one-GPU path).
+(`kaamer_exchange_merge`: integer sums, so the result is bit-identical to the one-GPU path).
 
-The product path is `ShardedSearcher`: C-ABI calls only (search, kaamer_exchange_pack,
-kaamer_exchange_merge, kaamer_topn_device) around ONE collective, no host synchronisation.
-The torch functions before it (`build_send`, `exchange`, `to_query_major`) are a
-device-agnostic restatement of the same routing with variable-size messages: they let the
-N>1 routing be tested with the gloo backend on CPU, where no kernel can run.
+`ShardedSearcher` is plumbing only: C-ABI calls (kaamer_search_device, kaamer_exchange_pack,
+kaamer_exchange_merge, kaamer_topn_device) around ONE equal-split collective.  Transports:
+
+  "rccl"   kaamer_rccl_alltoall on an ncclComm_t this module creates with ncclCommInitRank
+           (grouped ncclSend / ncclRecv; what a Go host would call) -- no host synchronisation
+  "torch"  torch.distributed.all_to_all_single on the device blocks (backend nccl = RCCL)
+  "host"   blocks staged through pinned host memory and exchanged with a CPU backend (gloo):
+           for ranks that share one device (RCCL cannot put two ranks on one GPU) and for
+           hosts without a peer path.  The blocks are the same bytes.
+
+(A single-process, multi-device index needs none of this: kaamer_index_open_sharded drives
+all shards from one process, see include/kaamer_hip.h.)
 """
 import ctypes as C
 
-import numpy as np
 import torch
 import torch.distributed as dist
 
 from . import abi, api
-
-
-def owner_perm(nq, world, device):
-    """queries grouped by owner rank (q % world), ascending inside a group"""
-    return torch.cat([torch.arange(d, nq, world, device=device) for d in range(world)]) if nq else \
-        torch.zeros(0, dtype=torch.int64, device=device)
-
-
-def n_owned(nq, world, rank):
-    return len(range(rank, nq, world))
-
-
-def _ranges_index(starts, counts):
-    """index tensor that concatenates [starts[i], starts[i]+counts[i])"""
-    total = int(counts.sum())
-    if total == 0:
-        return torch.zeros(0, dtype=torch.int64, device=starts.device)
-    dst = torch.cumsum(counts, 0) - counts
-    return torch.repeat_interleave(starts - dst, counts) + torch.arange(total, device=starts.device)
-
-
-def build_send(hit_off, hit_cnt, pid, km, fp, world):
-    """partial hit lists of ALL queries (first hit, count per query) -> buffers ordered by destination rank.
-
-    returns (cnt_p [nq] int64: per-query counts in owner order,
-             ents [n, 3] int32-like: the entries in the same order,
-             q_splits, e_splits: per-destination numbers of queries / entries)"""
-    nq = hit_cnt.numel()
-    dev = hit_off.device
-    cnt = hit_cnt.to(torch.int64)
-    perm = owner_perm(nq, world, dev)
-    cnt_p = cnt[perm]
-    idx = _ranges_index(hit_off[:nq].to(torch.int64)[perm], cnt_p)
-    ents = torch.stack([pid[idx], km[idx], fp[idx]], dim=1) if idx.numel() else \
-        torch.zeros((0, 3), dtype=pid.dtype, device=dev)
-    q_splits = [n_owned(nq, world, d) for d in range(world)]
-    bounds = np.cumsum([0] + q_splits)
-    csum = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(cnt_p, 0)])
-    edges = csum[torch.as_tensor(bounds, dtype=torch.int64, device=dev)].tolist()  # one host sync for all destinations
-    e_splits = [int(edges[d + 1] - edges[d]) for d in range(world)]
-    return cnt_p, ents.contiguous(), q_splits, e_splits
-
-
-def exchange(cnt_p, ents, q_splits, e_splits, rank, world, group=None):
-    """the one exchange step: all-to-all of the per-query counts, then of the entries.
-
-    returns (recv_cnt [world, n_owned] int64, recv_ents [m, 3]) with the entries in
-    source-major order (source 0's lists for my queries, then source 1's, ...)"""
-    mine = q_splits[rank]
-    recv_cnt = torch.empty(world * mine, dtype=cnt_p.dtype, device=cnt_p.device)
-    dist.all_to_all_single(recv_cnt, cnt_p.contiguous(), output_split_sizes=[mine] * world,
-                           input_split_sizes=q_splits, group=group)
-    recv_cnt = recv_cnt.view(world, mine)
-    in_splits = [int(x) for x in recv_cnt.sum(1).tolist()]
-    recv_ents = torch.empty((sum(in_splits), 3), dtype=ents.dtype, device=ents.device)
-    dist.all_to_all_single(recv_ents, ents, output_split_sizes=in_splits, input_split_sizes=e_splits, group=group)
-    return recv_cnt, recv_ents
-
-
-def to_query_major(recv_cnt, recv_ents):
-    """source-major received entries -> per-query contiguous (what kaamer_merge_device reads).
-
-    returns (ent_off [n_owned + 1] int64, ents [m, 3])"""
-    world, mine = recv_cnt.shape
-    dev = recv_cnt.device
-    src_base = torch.cumsum(recv_cnt.sum(1), 0) - recv_cnt.sum(1)                  # first entry of each source block
-    seg_start = src_base[:, None] + torch.cumsum(recv_cnt, 1) - recv_cnt           # [world, mine] start of (source, query)
-    # query-major order of the (query, source) segments
-    starts = seg_start.t().reshape(-1)
-    counts = recv_cnt.t().reshape(-1)
-    idx = _ranges_index(starts, counts)
-    tot_q = recv_cnt.sum(0)
-    ent_off = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(tot_q, 0)])
-    return ent_off, (recv_ents[idx] if idx.numel() else recv_ents[:0]).contiguous()
 
 
 class _DevView:
@@ -105,26 +37,82 @@ class _DevView:
 
 
 def dev_tensor(ptr, n, dtype):
-    typestr = {torch.int32: "<i4", torch.int64: "<i8"}[dtype]
+    typestr = {torch.int32: "<i4", torch.int64: "<i8", torch.uint8: "|u1"}[dtype]
     if n == 0:
         return torch.zeros(0, dtype=dtype, device="cuda")
     return torch.as_tensor(_DevView(ptr, n, typestr), device="cuda")
 
 
+class _NcclUniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]  # NCCL_UNIQUE_ID_BYTES
+
+
+def _rccl():
+    """librccl as the process already has it (torch's copy has the soname librccl.so.1), else the system's"""
+    for name in ("librccl.so.1", "librccl.so"):
+        try:
+            L = C.CDLL(name, mode=C.RTLD_GLOBAL)
+            break
+        except OSError:
+            L = None
+    if L is None:
+        raise ImportError("librccl is not loadable")
+    L.ncclGetUniqueId.argtypes = [C.POINTER(_NcclUniqueId)]
+    L.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _NcclUniqueId, C.c_int]
+    L.ncclCommDestroy.argtypes = [C.c_void_p]
+    L.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+    L.ncclGetErrorString.restype = C.c_char_p
+    L.ncclGetErrorString.argtypes = [C.c_int]
+    return L
+
+
+class RcclComm:
+    """An ncclComm_t of `world` ranks made with ncclGetUniqueId / ncclCommInitRank, the calls a Go host makes through
+    cgo (INTEGRATION.md §4b).  The unique id travels through `group` (any torch.distributed group of the same ranks;
+    world 1 needs none)."""
+
+    def __init__(self, rank, world, group=None):
+        self.L = _rccl()
+        uid = _NcclUniqueId()
+        if rank == 0:
+            self._chk(self.L.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+        if world > 1:
+            box = [bytes(uid.internal) if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=group)
+            C.memmove(C.byref(uid), box[0], 128)
+        self.handle = C.c_void_p()
+        self._chk(self.L.ncclCommInitRank(C.byref(self.handle), world, uid, rank), "ncclCommInitRank")
+        n = C.c_int()
+        self._chk(self.L.ncclCommCount(self.handle, C.byref(n)), "ncclCommCount")
+        self.world = n.value  # the rank count RCCL saw
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise RuntimeError("%s: %s" % (what, self.L.ncclGetErrorString(rc).decode()))
+
+    def close(self):
+        if self.handle:
+            self.L.ncclCommDestroy(self.handle)
+            self.handle = C.c_void_p()
+
+
+PHASES = ("search", "pack", "alltoall", "merge", "topn")
+
+
 class ShardedSearcher:
     """Rank-local driver of the sharded index: search my shard, pack, all-to-all, merge my queries, post-steps.
-    Every step is a C-ABI call enqueued on one stream (kaamer_search_device, kaamer_exchange_pack,
-    kaamer_exchange_merge, kaamer_topn_device); the transport is torch.distributed's all_to_all_single on
-    the packed blocks with EQUAL splits (backend nccl = RCCL: grouped send/recv over xGMI), so a step has no
-    host synchronisation at all.  Works for protein and for nucleotide / reads input (every rank translates;
-    the owner's post-steps use its own ORFs: orf_source)."""
+    Every compute step is a C-ABI call enqueued on one stream.  Works for protein and for nucleotide / reads input
+    (every rank translates; the owner's post-steps use its own ORFs: orf_source)."""
 
     def __init__(self, index, rank, world, max_seq_bytes, max_seqs, seq_type=abi.PROTEIN, max_entries_per_peer=1 << 20,
-                 group=None, max_hits=0, g_tier_slots=0, first_pos=None):
+                 group=None, max_hits=0, g_tier_slots=0, first_pos=None, transport="torch", comm=None):
         """first_pos: carry the lowest matching position of every hit through the exchange.  Default: as the reference
         fills PositionHits (search.go:416) -- nucleotide / reads input yes (SetBestStartCodon reads it), protein input no
-        (a third less to pack, send, unpack and merge)."""
+        (a third less to pack, send, unpack and merge).
+        transport: "rccl" (comm: an RcclComm; made here when None), "torch", or "host" (see the module docstring)."""
+        assert transport in ("rccl", "torch", "host")
         self.index, self.rank, self.world, self.group = index, rank, world, group
+        self.transport = transport
         self.nucl = seq_type in (abi.READS, abi.NUCLEOTIDE)
         if first_pos is None:
             first_pos = self.nucl
@@ -138,19 +126,69 @@ class ShardedSearcher:
         self.mws = api.Workspace(index, 64, L.q_cap, max_queries=L.q_cap, first_pos=fp, max_hits=world * L.e_cap,
                                  g_tier_slots=g_tier_slots)
         n = world * int(L.block_words)
+        self.block_bytes = 4 * int(L.block_words)
         self.send = torch.empty(n, dtype=torch.int32, device="cuda")
-        self.recv = torch.empty(n, dtype=torch.int32, device="cuda") if world > 1 else self.send
+        # (through RCCL the blocks really travel, also from a rank to itself: a receive buffer of its own)
+        self.recv = torch.empty(n, dtype=torch.int32, device="cuda") if (world > 1 or transport == "rccl") else self.send
+        self.comm, self._own_comm = comm, False
+        if transport == "rccl" and comm is None:
+            self.comm, self._own_comm = RcclComm(rank, world, group), True
+        if transport == "host" and world > 1:
+            self.h_send = torch.empty(n, dtype=torch.int32).pin_memory()
+            self.h_recv = torch.empty(n, dtype=torch.int32).pin_memory()
+        self.phase_ms = None
 
-    def step(self, d_seqs_ptr, d_off_ptr, n_seqs, seq_bytes, stream):
-        """`stream`: a torch.cuda.Stream (the collective is issued under it).  -> DeviceResult of the merged,
-        owned queries (query i of the result = query rank + i * world of the batch)"""
+    def _alltoall(self, stream):
         raw = stream.cuda_stream
-        self.ws.search_device(d_seqs_ptr, d_off_ptr, n_seqs, seq_bytes, stream=raw)
-        self.ws.exchange_pack(self.layout, self.send.data_ptr(), raw)
-        if self.world > 1:
+        if self.transport == "rccl":  # world 1 included: the send/recv pair with oneself goes through RCCL too
+            abi.check(abi.lib().kaamer_rccl_alltoall(self.comm.handle, self.send.data_ptr(), self.recv.data_ptr(),
+                                                     self.block_bytes, self.world, C.c_void_p(raw)))
+            return
+        if self.world == 1:
+            return
+        if self.transport == "torch":
             with torch.cuda.stream(stream):
                 dist.all_to_all_single(self.recv, self.send, group=self.group)
-        return self.mws.exchange_merge(self.layout, self.recv.data_ptr(), raw)
+            return
+        with torch.cuda.stream(stream):
+            self.h_send.copy_(self.send, non_blocking=True)
+        stream.synchronize()
+        dist.all_to_all_single(self.h_recv, self.h_send, group=self.group)
+        with torch.cuda.stream(stream):
+            self.recv.copy_(self.h_recv, non_blocking=True)
+
+    def step(self, d_seqs_ptr, d_off_ptr, n_seqs, seq_bytes, stream, topn=None, timed=False):
+        """`stream`: a torch.cuda.Stream.  -> DeviceResult of the merged, owned queries (query i of the result = query
+        rank + i * world of the batch).  topn: dict of kaamer_topn_device options to run the post-steps too (result in
+        self.last_topn).  timed: bracket every phase with events; their ms are added to self.phase_ms after a sync."""
+        raw = stream.cuda_stream
+        ev = []
+
+        def mark():
+            if timed:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(stream)
+                ev.append(e)
+        mark()
+        self.last_search = self.ws.search_device(d_seqs_ptr, d_off_ptr, n_seqs, seq_bytes, stream=raw)
+        mark()
+        self.ws.exchange_pack(self.layout, self.send.data_ptr(), raw)
+        mark()
+        self._alltoall(stream)
+        mark()
+        r = self.mws.exchange_merge(self.layout, self.recv.data_ptr(), raw)
+        mark()
+        self.last_topn = self.topn(stream, **topn) if topn is not None else None
+        mark()
+        if timed:
+            stream.synchronize()
+            if self.phase_ms is None:
+                self.phase_ms = dict.fromkeys(PHASES, 0.0)
+                self.phase_ms["batches"] = 0
+            for i, name in enumerate(PHASES):
+                self.phase_ms[name] += ev[i].elapsed_time(ev[i + 1])
+            self.phase_ms["batches"] += 1
+        return r
 
     def topn(self, stream, min_k_ratio=0.05, min_k_match=10, max_results=10):
         """the post-steps of the reference's drivers on the merged results (SetBestStartCodon for nucleotide input)"""
@@ -158,6 +196,23 @@ class ShardedSearcher:
                                     orf_source=self.ws, q_first=self.rank, q_stride=self.world, stream=stream.cuda_stream)
 
     def finish(self, stream):
-        """-> (counters of the local search, counters of the merge); raises on a capacity overflow"""
-        c = self.ws.finish(stream.cuda_stream)
-        return c, self.mws.finish(stream.cuda_stream)
+        """-> (counters of the local search, counters of the merge).  BOTH workspaces are finished before an error of
+        either is raised: a rank whose own search failed still learns what its merge saw, and a rank whose merge was
+        handed a failed peer's blocks raises too (every rank of the batch raises, none hangs at the next collective)."""
+        err = None
+        out = []
+        for w in (self.ws, self.mws):
+            try:
+                out.append(w.finish(stream.cuda_stream))
+            except abi.KaamerError as e:
+                out.append(None)
+                err = err or e
+        if err is not None:
+            raise err
+        return out[0], out[1]
+
+    def close(self):
+        if self._own_comm:
+            self.comm.close()
+        self.ws.close()
+        self.mws.close()

@@ -1,6 +1,16 @@
-"""Sharded index: the exchange plumbing with world_size-2 gloo on CPU, and the
-device merge kernel with two shards on one GPU."""
+"""Sharded index.
+
+CPU (`-m "not gpu"`): world_size-2 gloo runs of the exchange -- the product's fixed-size block format (restated in
+numpy in tests/blockfmt.py, sized by the library's own kaamer_exchange_layout_init) carried by the product's transport
+pattern (one all_to_all_single with EQUAL splits), and the variable-size routing restatement of tests/sharded_ref.py.
+No kernel can run there, so the partial lists come from the oracle.
+
+GPU (`-m gpu`): the PRODUCT path -- kaamer_search_device -> kaamer_exchange_pack -> all-to-all -> kaamer_exchange_merge
+-> kaamer_topn_device -- between two real processes that share GPU 0 (blocks staged through the host and carried by
+gloo: RCCL cannot put two ranks on one device), through kaamer_rccl_alltoall on a real one-rank ncclComm_t, and in one
+process with the blocks routed by slicing.  Results against the oracle on the WHOLE database."""
 import os
+import socket
 import sys
 
 import numpy as np
@@ -16,6 +26,15 @@ def _partial_csr(oracle, oix, seqs):
         if oracle.size_in_kmer(s) >= 7:
             p, k, pos = oix.search(s, want_positions=True)
             pid += p.tolist(); km += k.tolist(); fp += [int(np.argmax(pos[i])) for i in range(len(p))]
+        off.append(len(pid))
+    return (np.array(off, np.int64), np.array(pid, np.int32), np.array(km, np.int32), np.array(fp, np.int32))
+
+
+def _partial_csr_orfs(oracle, oix, orfs):
+    off, pid, km, fp = [0], [], [], []
+    for o in orfs:
+        p, k, pos = oix.search(o["seq"], want_positions=True)
+        pid += p.tolist(); km += k.tolist(); fp += [int(np.argmax(pos[i])) for i in range(len(p))]
         off.append(len(pid))
     return (np.array(off, np.int64), np.array(pid, np.int32), np.array(km, np.int32), np.array(fp, np.int32))
 
@@ -41,128 +60,115 @@ def _shard_pairs(klib, oracle, db, shard, n_shards):
     return keys[m], ids[m]
 
 
-def _gloo_worker(rank, world, port, ret):
-    sys.path.insert(0, ROOT)
-    import torch
-    import torch.distributed as dist
-    from kaamer_amd import abi, sharded, workload
-    from oracle import oracle as O
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        klib = abi.lib()
-        db = workload.make_db(60, seed=3)
-        seqs = workload.unpack(workload.make_protein_queries(db, 23, seed=4)) + [b"AAAA", b""]
-        k, i = _shard_pairs(klib, O, db, rank, world)
-        oix = O.Index.from_pairs(k, i)
-        off, pid, km, fp = (torch.from_numpy(x) for x in _partial_csr(O, oix, seqs))
-        cnt_p, ents, qs, es = sharded.build_send(off, (off[1:] - off[:-1]).to(torch.int32), pid, km, fp, world)
-        recv_cnt, recv_ents = sharded.exchange(cnt_p, ents, qs, es, rank, world)
-        ent_off, q_ents = sharded.to_query_major(recv_cnt, recv_ents)
-        merged = _numpy_merge(ent_off.numpy(), q_ents.numpy())
-        full = O.Index.from_proteins(None, packed=db)
-        exp_off, epid, ekm, efp = _partial_csr(O, full, seqs)
-        owned = list(range(rank, len(seqs), world))
-        assert len(merged) == len(owned)
-        n = 0
-        for j, q in enumerate(owned):
-            exp = {int(p): (int(c), int(f)) for p, c, f in zip(epid[exp_off[q]:exp_off[q + 1]], ekm[exp_off[q]:exp_off[q + 1]],
-                                                             efp[exp_off[q]:exp_off[q + 1]])}
-            assert merged[j] == exp, (rank, q)
-            n += len(exp)
-        ret[rank] = n
-    finally:
-        dist.destroy_process_group()
-
-
-def _gloo_worker_reads(rank, world, port, ret):
-    """reads over two shards: every rank translates, searches its shard, one exchange by ORF owner, merge, then the
-    reference's post-steps (sortMapByValue, SetBestStartCodon, FilterResults: the product's host entry points) --
-    against the oracle on the whole database"""
-    sys.path.insert(0, ROOT)
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import ctypes as C
-    import torch
-    import torch.distributed as dist
-    from kaamer_amd import abi, sharded, workload
-    from oracle import oracle as O
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        klib = abi.lib()
-        db = workload.make_db(80, seed=3)
-        reads = workload.unpack(workload.make_reads(db, 40, seed=5))
-        orfs = [o for r in reads for o in O.get_orfs(r)]          # every rank translates: same ORFs, same order
-        k, i = _shard_pairs(klib, O, db, rank, world)
-        oix = O.Index.from_pairs(k, i)
-        off, pid, km, fp = (torch.from_numpy(x) for x in _partial_csr_orfs(O, oix, orfs))
-        cnt_p, ents, qs, es = sharded.build_send(off, (off[1:] - off[:-1]).to(torch.int32), pid, km, fp, world)
-        recv_cnt, recv_ents = sharded.exchange(cnt_p, ents, qs, es, rank, world)
-        ent_off, q_ents = sharded.to_query_major(recv_cnt, recv_ents)
-        merged = _numpy_merge(ent_off.numpy(), q_ents.numpy())
-        full = O.Index.from_proteins(None, packed=db)
-        owned = list(range(rank, len(orfs), world))
-        assert len(merged) == len(owned)
-        n = 0
-        for j, q in enumerate(owned):
-            o = orfs[q]
-            exp_full, exp_rep = _oracle_report(O, full, o, True)
-            assert merged[j] == exp_full, (rank, q)
-            # post-steps on the merged list, host entry points of the product library
-            ids = np.array(sorted(merged[j]), np.uint32)
-            kms = np.array([merged[j][int(p)][0] for p in ids], np.uint32)
-            fps = np.array([merged[j][int(p)][1] for p in ids], np.uint32)
-            order = np.zeros(len(ids), np.uint32)
-            klib.kaamer_sort_hits(ids.ctypes.data, kms.ctypes.data, len(ids), order.ctypes.data)
-            ids, kms, fps = ids[order], kms[order], fps[order]
-            keep = 0
-            if len(kms) and kms[0] >= 10:                      # search_fastq.go:119
-                sa = np.array(o["starts"], np.int32)
-                aa = o["seq"].encode("latin-1")
-                sp, sz = C.c_int32(o["start"]), C.c_int32(O.size_in_kmer(o["seq"]))
-                klib.kaamer_set_best_start_codon(kms.ctypes.data, fps.ctypes.data, len(kms), sa.ctypes.data, len(sa), int(o["plus"]),
-                                                 aa, len(aa), C.byref(sp), C.byref(sz))
-                keep = int(klib.kaamer_filter_results(kms.ctypes.data, len(kms), sz.value, 0.05, 10, 10))
-            assert list(zip(ids[:keep].tolist(), kms[:keep].tolist())) == exp_rep, (rank, q)
-            n += len(exp_full)
-        ret[rank] = n
-    finally:
-        dist.destroy_process_group()
-
-
-def _partial_csr_orfs(oracle, oix, orfs):
-    off, pid, km, fp = [0], [], [], []
-    for o in orfs:
-        p, k, pos = oix.search(o["seq"], want_positions=True)
-        pid += p.tolist(); km += k.tolist(); fp += [int(np.argmax(pos[i])) for i in range(len(p))]
-        off.append(len(pid))
-    return (np.array(off, np.int64), np.array(pid, np.int32), np.array(km, np.int32), np.array(fp, np.int32))
-
-
-@pytest.mark.parametrize("worker", ["protein", "reads"])
-def test_exchange_gloo_world2(klib, oracle, worker):
-    import torch.multiprocessing as mp
-    import socket
+def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    return port
+
+
+def _spawn(target, world, args=(), timeout=600):
+    """world processes of `target(rank, world, port, ret, *args)`; -> ret as a dict"""
+    import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
-    target = _gloo_worker if worker == "protein" else _gloo_worker_reads
+    port = _free_port()
     with ctx.Manager() as mgr:
         ret = mgr.dict()
-        procs = [ctx.Process(target=target, args=(r, 2, port, ret)) for r in range(2)]
+        procs = [ctx.Process(target=target, args=(r, world, port, ret) + tuple(args)) for r in range(world)]
         for p in procs:
             p.start()
         for p in procs:
-            p.join(180)
+            p.join(timeout)
+        alive = [p for p in procs if p.is_alive()]
+        for p in alive:
+            p.terminate()
+        assert not alive, "a rank did not finish"
         assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
-        assert len(ret) == 2 and sum(ret.values()) > 50
+        return dict(ret)
+
+
+def _init_gloo(rank, world, port):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+
+def _gloo_worker_blocks(rank, world, port, ret, reads):
+    """CPU: the block format + the equal-split collective between two ranks; partial lists from the oracle"""
+    for p_ in (ROOT, os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p_)
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    import blockfmt
+    from kaamer_amd import abi, workload
+    from oracle import oracle as O
+    _init_gloo(rank, world, port)
+    try:
+        klib = abi.lib()
+        db = workload.make_db(80, seed=3)
+        if reads:
+            rl = workload.unpack(workload.make_reads(db, 40, seed=5))
+            queries = [o for r in rl for o in O.get_orfs(r)]          # every rank translates: same ORFs, same order
+        else:
+            queries = workload.unpack(workload.make_protein_queries(db, 23, seed=4)) + [b"AAAA", b""]
+        k, i = _shard_pairs(klib, O, db, rank, world)
+        oix = O.Index.from_pairs(k, i)
+        off, pid, km, fp = _partial_csr_orfs(O, oix, queries) if reads else _partial_csr(O, oix, queries)
+        nq = len(queries)
+        L = abi.ExchangeLayout()
+        abi.check(klib.kaamer_exchange_layout_init(world, rank, nq, 1 << 12, C.byref(L)))
+        send = blockfmt.pack_blocks(L, nq, off, np.diff(off), pid.view(np.uint32), km.view(np.uint32), fp.view(np.uint32), True)
+        t_send = torch.from_numpy(send.view(np.int32))
+        t_recv = torch.empty_like(t_send)
+        dist.all_to_all_single(t_recv, t_send)                       # equal splits: world blocks of block_words words
+        merged = blockfmt.unpack_merge(L, t_recv.numpy().view(np.uint32), True)
+        full = O.Index.from_proteins(None, packed=db)
+        owned = list(range(rank, nq, world))
+        assert len(merged) == len(owned)
+        n = 0
+        for j, q in enumerate(owned):
+            exp_full, exp_rep = _oracle_report(O, full, queries[q], reads)
+            assert merged[j] == exp_full, (rank, q)
+            if reads:  # post-steps on the merged list, host entry points of the product library
+                o = queries[q]
+                ids = np.array(sorted(merged[j]), np.uint32)
+                kms = np.array([merged[j][int(p)][0] for p in ids], np.uint32)
+                fps = np.array([merged[j][int(p)][1] for p in ids], np.uint32)
+                order = np.zeros(len(ids), np.uint32)
+                klib.kaamer_sort_hits(ids.ctypes.data, kms.ctypes.data, len(ids), order.ctypes.data)
+                ids, kms, fps = ids[order], kms[order], fps[order]
+                keep = 0
+                if len(kms) and kms[0] >= 10:                      # search_fastq.go:119
+                    sa = np.array(o["starts"], np.int32)
+                    aa = o["seq"].encode("latin-1")
+                    sp, sz = C.c_int32(o["start"]), C.c_int32(O.size_in_kmer(o["seq"]))
+                    klib.kaamer_set_best_start_codon(kms.ctypes.data, fps.ctypes.data, len(kms), sa.ctypes.data, len(sa), int(o["plus"]),
+                                                     aa, len(aa), C.byref(sp), C.byref(sz))
+                    keep = int(klib.kaamer_filter_results(kms.ctypes.data, len(kms), sz.value, 0.05, 10, 10))
+                assert list(zip(ids[:keep].tolist(), kms[:keep].tolist())) == exp_rep, (rank, q)
+            n += len(exp_full)
+        # a sender whose search failed: every owner refuses its blocks
+        bad = blockfmt.pack_blocks(L, nq, off, np.diff(off), pid.view(np.uint32), km.view(np.uint32), fp.view(np.uint32), True,
+                                   src_status=1 if rank == 1 else 0)
+        t_bad = torch.from_numpy(bad.view(np.int32))
+        dist.all_to_all_single(t_recv, t_bad)
+        with pytest.raises(ValueError):
+            blockfmt.unpack_merge(L, t_recv.numpy().view(np.uint32), True)
+        ret[rank] = n
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("reads", [False, True], ids=["protein", "reads"])
+def test_exchange_gloo_world2(klib, oracle, reads):
+    ret = _spawn(_gloo_worker_blocks, 2, (reads,), timeout=180)
+    assert len(ret) == 2 and sum(ret.values()) > 50
 
 
 def test_exchange_helpers_single_process():
     """routing identities of build_send / to_query_major without a process group"""
     import torch
-    from kaamer_amd import sharded
+    import sharded_ref as sharded
     rng = np.random.default_rng(0)
     world, nq = 3, 17
     cnt = rng.integers(0, 5, nq)
@@ -180,6 +186,8 @@ def test_exchange_helpers_single_process():
     ent_off, q_ents = sharded.to_query_major(recv_cnt, recv)
     exp = torch.cat([pid[off[q]:off[q + 1]] for q in range(1, nq, world)])
     assert torch.equal(q_ents[:, 0], exp) and ent_off[-1] == len(exp)
+
+
 
 
 def _route(sends, layouts, d):
@@ -306,6 +314,7 @@ def test_sharded_through_the_c_abi(klib, oracle, gpu_device, reads, first_pos):
 def test_two_shards_merge_on_one_gpu(klib, oracle, gpu_device):
     """shard the table in two, search both shards, route the partial lists in-process, merge on the device"""
     import torch
+    import sharded_ref
     from kaamer_amd import api, sharded, workload
     world = 2
     db = workload.make_db(400, seed=6)
@@ -326,7 +335,7 @@ def test_two_shards_merge_on_one_gpu(klib, oracle, gpu_device):
         total_lookups += c["n_lookup"]
         nh = int(res.hit_capacity)
         hit_off = sharded.dev_tensor(res.d_hit_off, n_seqs, torch.int64)
-        sends.append(sharded.build_send(hit_off, sharded.dev_tensor(res.d_hit_cnt, n_seqs, torch.int32),
+        sends.append(sharded_ref.build_send(hit_off, sharded.dev_tensor(res.d_hit_cnt, n_seqs, torch.int32),
                                         sharded.dev_tensor(res.d_hit_pid, nh, torch.int32),
                                         sharded.dev_tensor(res.d_hit_kmatch, nh, torch.int32),
                                         sharded.dev_tensor(res.d_hit_first_pos, nh, torch.int32), world))
@@ -342,7 +351,7 @@ def test_two_shards_merge_on_one_gpu(klib, oracle, gpu_device):
             qb, eb = np.cumsum([0] + qs), np.cumsum([0] + es)
             rc.append(cnt_p[qb[d]:qb[d + 1]])
             re.append(ents[eb[d]:eb[d + 1]])
-        ent_off, q_ents = sharded.to_query_major(torch.stack(rc), torch.cat(re))
+        ent_off, q_ents = sharded_ref.to_query_major(torch.stack(rc), torch.cat(re))
         cols = [q_ents[:, i].contiguous() for i in range(3)]
         m = mws.merge_device(ent_off.data_ptr(), cols[0].data_ptr(), cols[1].data_ptr(), cols[2].data_ptr(),
                              ent_off.numel() - 1, int(q_ents.shape[0]), stream=st)
@@ -363,3 +372,166 @@ def test_two_shards_merge_on_one_gpu(klib, oracle, gpu_device):
             a, b = int(hit_off[j]), int(hit_off[j]) + int(hit_cnt[j])
             got = {int(x): (int(y), int(z)) for x, y, z in zip(pid[a:b], km[a:b], fp[a:b])}
             assert got == exp, (d, q)
+
+
+def _gpu_worker(rank, world, port, ret, scenario):
+    """GPU: one of `world` processes that share GPU 0.  The product's ShardedSearcher end to end; blocks staged through
+    the host and carried by gloo.  scenario: "protein" | "reads" | "fail" (rank 1's G-tier arena is too small)."""
+    for p_ in (ROOT, os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p_)
+    import torch
+    import torch.distributed as dist
+    import blockfmt
+    from kaamer_amd import abi, api, sharded, workload
+    from oracle import oracle as O
+    _init_gloo(rank, world, port)
+    try:
+        torch.cuda.set_device(0)
+        reads = scenario == "reads"
+        g_slots = 0
+        if scenario == "fail":
+            rng = np.random.default_rng(4)
+            alpha = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
+            core = bytes(alpha[rng.integers(0, 20, 40)])
+            seqs_db = [bytes(alpha[rng.integers(0, 20, 8)]) + core[(i % 5):] + bytes(alpha[rng.integers(0, 20, 8)]) for i in range(9000)]
+            db = api.pack_sequences(seqs_db)
+            queries = [core, seqs_db[7], b"ACDEFGHIKLMNPQRSTVWY"]
+            q = api.pack_sequences(queries)
+            seq_type = abi.PROTEIN
+            g_slots = 4096 if rank == 1 else 0   # 9000 distinct hits per shard for `core`: needs the HBM tier
+        else:
+            db = workload.make_db(600, seed=6)
+            if reads:
+                q = workload.make_reads(db, 300, seed=12)
+                queries = [o for r in workload.unpack(q) for o in O.get_orfs(r)]
+                seq_type = abi.READS
+            else:
+                queries = workload.unpack(workload.make_protein_queries(db, 150, seed=7)) + [max(workload.unpack(db), key=len), b"AAAAAAA", b""]
+                q = api.pack_sequences(queries)
+                seq_type = abi.PROTEIN
+        buf, offs = q
+        n_seqs = len(offs) - 1
+        ix = api.Index.from_image(api.Image.from_proteins(packed=db, shard=rank, n_shards=world), 0)
+        ss = sharded.ShardedSearcher(ix, rank, world, len(buf), n_seqs, seq_type=seq_type, max_entries_per_peer=1 << 16,
+                                     transport="host", g_tier_slots=g_slots, first_pos=True)
+        d_buf = torch.from_numpy(buf).cuda()
+        d_off = torch.from_numpy(offs.view(np.int64)).cuda()
+        st = torch.cuda.current_stream()
+        m = ss.step(d_buf.data_ptr(), d_off.data_ptr(), n_seqs, len(buf), st, topn={})
+        if scenario == "fail":
+            # rank 1's search ran out of its arena: BOTH ranks report it (rank 0 through the blocks it received), none hangs
+            try:
+                ss.finish(st)
+                ret[rank] = "no error"
+            except abi.KaamerError as e:
+                ret[rank] = e.code
+            dist.barrier()
+            return
+        cs, cm = ss.finish(st)
+        # the blocks the device packed == the numpy restatement of the format applied to the device's own partial lists
+        r = ss.last_search
+        nq = cs["n_queries"] if reads else n_seqs
+        assert nq == len(queries)
+        cap = int(r.hit_capacity)
+        h_off = sharded.dev_tensor(r.d_hit_off, nq, torch.int64).cpu().numpy()
+        h_cnt = sharded.dev_tensor(r.d_hit_cnt, nq, torch.int32).cpu().numpy()
+        h_pid, h_km, h_fp = (sharded.dev_tensor(x, cap, torch.int32).cpu().numpy().view(np.uint32)
+                             for x in (r.d_hit_pid, r.d_hit_kmatch, r.d_hit_first_pos))
+        want = blockfmt.pack_blocks(ss.layout, nq, h_off, h_cnt, h_pid, h_km, h_fp, True)
+        got = ss.send.cpu().numpy().view(np.uint32)
+        mask = blockfmt.defined_words(ss.layout, want, True)
+        assert np.array_equal(got[mask], want[mask]), "device blocks differ from the documented format"
+        # merged + reported results of the owned queries vs the oracle on the WHOLE database
+        full = O.Index.from_proteins(None, packed=db)
+        owned = list(range(rank, len(queries), world))
+        t = ss.last_topn
+        hit_off = sharded.dev_tensor(m.d_hit_off, len(owned), torch.int64).cpu().numpy()
+        hit_cnt = sharded.dev_tensor(m.d_hit_cnt, len(owned), torch.int32).cpu().numpy()
+        nh = int(m.hit_capacity)
+        assert int(hit_cnt.sum()) == cm["n_hits"]
+        pid = sharded.dev_tensor(m.d_hit_pid, nh, torch.int32).cpu().numpy().view(np.uint32)
+        km = sharded.dev_tensor(m.d_hit_kmatch, nh, torch.int32).cpu().numpy()
+        fp = sharded.dev_tensor(m.d_hit_first_pos, nh, torch.int32).cpu().numpy()
+        tc = sharded.dev_tensor(t.d_top_cnt, len(owned), torch.int32).cpu().numpy()
+        tp = sharded.dev_tensor(t.d_top_pid, len(owned) * 10, torch.int32).cpu().numpy().view(np.uint32).reshape(-1, 10)
+        tk = sharded.dev_tensor(t.d_top_kmatch, len(owned) * 10, torch.int32).cpu().numpy().reshape(-1, 10)
+        n = 0
+        for j, qi in enumerate(owned):
+            exp_full, exp_rep = _oracle_report(O, full, queries[qi], reads)
+            a, b = int(hit_off[j]), int(hit_off[j]) + int(hit_cnt[j])
+            got_q = {int(x): (int(y), int(z)) for x, y, z in zip(pid[a:b], km[a:b], fp[a:b])}
+            assert got_q == exp_full, (rank, qi)
+            k = len(exp_rep)
+            assert int(tc[j]) == k, (rank, qi)
+            assert list(zip(tp[j, :k].tolist(), tk[j, :k].tolist())) == exp_rep, (rank, qi)
+            n += len(got_q)
+        ret[rank] = n
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scenario", ["protein", "reads"])
+def test_two_processes_one_gpu_product_path(klib, oracle, gpu_device, scenario):
+    """configs[3] in small: two ranks (two OS processes on GPU 0), each with its hash-prefix shard; the product's
+    search -> kaamer_exchange_pack -> all-to-all -> kaamer_exchange_merge -> kaamer_topn_device(orf_source) with the
+    q mod W ownership arithmetic across REAL ranks; merged hit maps, first positions and reported hits of every owned
+    query vs the oracle on the whole database; the device's blocks vs the documented format."""
+    ret = _spawn(_gpu_worker, 2, (scenario,))
+    assert len(ret) == 2 and sum(ret.values()) > 500, ret
+
+
+@pytest.mark.gpu
+def test_failed_peer_is_reported_by_every_rank(klib, oracle, gpu_device):
+    """rank 1's search exceeds its G-tier arena: its blocks say so, and rank 0 -- whose own search and merge were
+    fine -- raises KAAMER_E_CAPACITY too instead of keeping truncated results and hanging at the next collective"""
+    from kaamer_amd import abi
+    ret = _spawn(_gpu_worker, 2, ("fail",))
+    assert ret == {0: abi.E_CAPACITY, 1: abi.E_CAPACITY}, ret
+
+
+@pytest.mark.gpu
+def test_rccl_alltoall_on_a_real_communicator(klib, oracle, gpu_device):
+    """kaamer_rccl_alltoall with an ncclComm_t made by ncclGetUniqueId / ncclCommInitRank (one rank: all one GPU
+    allows): the block really goes through RCCL's grouped send/recv, and the sharded step over that transport equals
+    the unsharded result"""
+    import ctypes as C
+    import torch
+    from kaamer_amd import abi, api, sharded, workload
+    comm = sharded.RcclComm(0, 1)
+    assert comm.world == 1
+    st = torch.cuda.current_stream()
+    src = torch.randint(-2**31, 2**31 - 1, (1 << 18,), dtype=torch.int32, device="cuda")
+    dst = torch.zeros_like(src)
+    abi.check(klib.kaamer_rccl_alltoall(comm.handle, src.data_ptr(), dst.data_ptr(), src.numel() * 4, 1, C.c_void_p(st.cuda_stream)))
+    st.synchronize()
+    assert torch.equal(src, dst)
+    # bad arguments are refused, not passed to RCCL
+    assert klib.kaamer_rccl_alltoall(None, src.data_ptr(), dst.data_ptr(), 16, 1, C.c_void_p(st.cuda_stream)) == abi.E_ARG
+    db = workload.make_db(400, seed=6)
+    seqs = workload.unpack(workload.make_protein_queries(db, 120, seed=7)) + [b"AAAAAAA", b""]
+    buf, offs = api.pack_sequences(seqs)
+    ix = api.Index.from_image(api.Image.from_proteins(packed=db), gpu_device)
+    ss = sharded.ShardedSearcher(ix, 0, 1, len(buf), len(seqs), max_entries_per_peer=1 << 16, transport="rccl", comm=comm)
+    d_buf = torch.from_numpy(buf).cuda()
+    d_off = torch.from_numpy(offs.view(np.int64)).cuda()
+    m = ss.step(d_buf.data_ptr(), d_off.data_ptr(), len(seqs), len(buf), st)
+    ss.finish(st)
+    full = oracle.Index.from_proteins(None, packed=db)
+    hit_off = sharded.dev_tensor(m.d_hit_off, len(seqs), torch.int64).cpu().numpy()
+    hit_cnt = sharded.dev_tensor(m.d_hit_cnt, len(seqs), torch.int32).cpu().numpy()
+    pid = sharded.dev_tensor(m.d_hit_pid, int(m.hit_capacity), torch.int32).cpu().numpy().view(np.uint32)
+    km = sharded.dev_tensor(m.d_hit_kmatch, int(m.hit_capacity), torch.int32).cpu().numpy()
+    n = 0
+    for i, s in enumerate(seqs):
+        exp = {}
+        if oracle.size_in_kmer(s) >= 7:
+            p, k, _ = full.search(s)
+            exp = dict(zip(p.tolist(), k.tolist()))
+        a = int(hit_off[i])
+        assert dict(zip(pid[a:a + int(hit_cnt[i])].tolist(), km[a:a + int(hit_cnt[i])].tolist())) == exp, i
+        n += len(exp)
+    assert n > 500
+    ss.close()
+    comm.close()
