@@ -121,9 +121,12 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--db-proteins", type=int, default=560000)
-    ap.add_argument("--db", choices=["sp", "zipf"], default="sp",
+    ap.add_argument("--db", choices=["sp", "zipf", "zipf-mid", "ur-lite"], default="sp",
                     help="sp = DB-SP of SURVEY 8d (default); zipf = the same size with Zipf-distributed shared motifs "
-                         "(postings lists of 1e4 and more): a reported secondary line, never the headline")
+                         "(postings lists of 1e4 and more), zipf-mid = a middle skew (longest list ~1e3): reported secondary "
+                         "lines, never the headline; ur-lite = the DB-SP generator scaled to --ur-residues (default 5e9: "
+                         "a database that is actually sharded; use with --mode sharded, every rank builds only its shard)")
+    ap.add_argument("--ur-residues", type=float, default=5e9)
     ap.add_argument("--workload", choices=["protein", "reads", "mix"], default="protein",
                     help="protein = BASELINE configs[1] (default); reads = configs[2]: 150-nt reads, 6-frame path; "
                          "mix = Q-mix of configs[4]: 100/150/250-nt reads + 5 %% long reads")
@@ -144,6 +147,13 @@ def main():
                     help="N>1: replicas = every rank holds the table and its own batches (default; the DB fits one GPU); "
                          "sharded = the table is split by hash prefix, all ranks search one common batch, partial hit "
                          "lists are exchanged once per batch and merged by the query's owner")
+    ap.add_argument("--transport", choices=["rccl", "torch"], default="rccl",
+                    help="sharded mode: rccl = kaamer_rccl_alltoall on an ncclComm_t made with ncclCommInitRank (what a Go host "
+                         "calls); torch = torch.distributed.all_to_all_single (backend nccl = RCCL)")
+    ap.add_argument("--sharded-leg", type=int, default=1,
+                    help="replicas mode with N > 1: after the timed region also run a short pass of the hash-prefix sharded index "
+                         "(configs[3]'s data path: search -> pack -> RCCL all-to-all -> merge -> top-N) on the same database and "
+                         "report it under `sharded_leg` (per-phase ms, bytes exchanged, the rank count RCCL saw); 0 = skip")
     ap.add_argument("--time-every", type=int, default=16,
                     help="bracket the kernels of every k-th timed launch with HIP events (roofline.achieved is their average)")
     ap.add_argument("--post", type=int, default=0,
@@ -176,12 +186,16 @@ def main():
     if args.queries <= 0:
         args.queries = 1000000 if nucl else 10000
     if args.batches_per_step <= 0:
-        args.batches_per_step = 3 if nucl else (20 if args.db == "zipf" else 200)
+        args.batches_per_step = 3 if nucl else (20 if args.db.startswith("zipf") else 200)
     if args.inflight <= 0:
-        args.inflight = 1 if (nucl or args.mode == "sharded" or args.db == "zipf") else 3
-    if args.db == "zipf":
+        args.inflight = 1 if (nucl or args.mode == "sharded" or args.db.startswith("zipf")) else 3
+    if args.db.startswith("zipf"):
         args.g_tier_slots = args.g_tier_slots or (1 << 30)
         args.max_hits = args.max_hits or (1 << 28)
+    if args.db == "ur-lite":
+        args.db_proteins = int(args.ur_residues / 358.5)   # mean length of workload._lengths
+    if args.db_proteins > 3000000:
+        args.check = 0   # the oracle's index of the whole database does not fit the bounded check of a bench run
     _tame_malloc()
     import numpy as np
     import torch
@@ -202,7 +216,12 @@ def main():
     from kaamer_amd import abi, api, workload
 
     t0 = time.time()
-    db = workload.make_db(args.db_proteins) if args.db == "sp" else workload.make_db_zipf(args.db_proteins)
+    if args.db == "zipf":
+        db = workload.make_db_zipf(args.db_proteins)
+    elif args.db == "zipf-mid":   # a tenth of the motif reuse: longest postings list ~1e3
+        db = workload.make_db_zipf(args.db_proteins, zipf_a=0.45, per_residues=240)
+    else:
+        db = workload.make_db(args.db_proteins)
     log("DB (%s): %d proteins, %d residues (%.1fs)" % (args.db, args.db_proteins, int(db[1][-1]), time.time() - t0))
     t0 = time.time()
     img = api.Image.from_proteins(packed=db, load_factor=args.load_factor,
@@ -235,12 +254,39 @@ def main():
                  compact=bool(args.compact))
     stream = torch.cuda.current_stream().cuda_stream
 
+    def exchange_entries():
+        return args.exchange_entries or ((96 << 20) if nucl else (4 << 20)) // world + (1 << 16)
+
+    def exchange_report(searcher, tstream, bufs, offs, sizes, n_pass=6):
+        """per-phase times of the sharded step (events around every phase, one batch at a time), what travelled, and
+        how many ranks the RCCL communicator has"""
+        from kaamer_amd import sharded
+        searcher.phase_ms = None
+        for i in range(n_pass):
+            b = i % len(bufs)
+            searcher.step(bufs[b].data_ptr(), offs[b].data_ptr(), args.queries, sizes[b], tstream,
+                          topn={}, timed=True)
+        searcher.finish(tstream)
+        ph = searcher.phase_ms
+        L = searcher.layout
+        bw, W = int(L.block_words), int(L.world)
+        hdr = torch.stack([searcher.send[d * bw:d * bw + 4] for d in range(W)]).cpu().numpy()   # [entries, status, nq, owned]
+        words = 3 if searcher.ws_first_pos else 2
+        payload = int(sum(4 * (4 + int(h[3]) + words * int(h[0])) for h in hdr))
+        return {"transport": searcher.transport,
+                "rccl_comm_ranks": searcher.comm.world if searcher.comm is not None else None,
+                "phase_ms_per_batch": {k: ph[k] / ph["batches"] for k in sharded.PHASES},
+                "phase_batches": ph["batches"],
+                "wire_bytes_per_rank_per_batch": W * searcher.block_bytes,      # fixed-size blocks: what the all-to-all moves
+                "payload_bytes_per_rank_per_batch": payload,                     # headers + counts + entries actually packed
+                "block_entry_capacity": int(L.e_cap), "entries_packed_per_block": [int(h[0]) for h in hdr]}
+
     if sharded_mode:
         from kaamer_amd import sharded
         tstream = torch.cuda.current_stream()
-        ent = args.exchange_entries or ((96 << 20) if nucl else (4 << 20)) // world + (1 << 16)
         searcher = sharded.ShardedSearcher(ix, rank, world, max_bytes, args.queries, seq_type=seq_type,
-                                           max_entries_per_peer=ent, max_hits=(64 << 20) if nucl else 0)
+                                           max_entries_per_peer=exchange_entries(), max_hits=(64 << 20) if nucl else 0,
+                                           transport=args.transport)
 
         def launch(i):
             b = i % n_distinct
@@ -318,6 +364,66 @@ def main():
                 wss[0].topn_device(0.05, 10, 10, best_start_codon=nucl, stream=streams[0])
         wss[0].finish(streams[0])
         tm_alone = wss[0].kernel_ms_sum()
+
+    exch = exchange_report(searcher, tstream, d_bufs, d_offs, [len(q[0]) for q in batches]) if sharded_mode else None
+
+    def sharded_leg(n_batches=12):
+        """configs[3]'s data path on this run's database: every rank builds and holds only its hash-prefix shard, all
+        ranks search ONE common batch, partial hit lists go to the query's owner over RCCL, the owner merges and runs
+        the post-steps.  A short secondary measurement next to the replicas headline (strong scaling: the batch is fixed)."""
+        from kaamer_amd import sharded
+        t0 = time.time()
+        simg = api.Image.from_proteins(packed=db, load_factor=args.load_factor, shard=rank, n_shards=world)
+        sst = simg.stats()
+        six = api.Index.from_image(simg, local_rank)
+        simg.close()
+        build_s = time.time() - t0
+        cb = []
+        for b in range(2):  # the same batches on every rank
+            seed = workload.SEED + 501 + b
+            cb.append(workload.make_reads(db, args.queries, seed=seed) if args.workload == "reads" else
+                      workload.make_reads_mix(db, args.queries, seed=seed) if args.workload == "mix" else
+                      workload.make_protein_queries(db, args.queries, seed=seed))
+        cbuf = [torch.from_numpy(q[0]).cuda() for q in cb]
+        coff = [torch.from_numpy(q[1].view(np.int64)).cuda() for q in cb]
+        sizes = [len(q[0]) for q in cb]
+        ts = torch.cuda.current_stream()
+        ss = sharded.ShardedSearcher(six, rank, world, max(sizes), args.queries, seq_type=seq_type,
+                                     max_entries_per_peer=exchange_entries(), max_hits=(64 << 20) if nucl else 0,
+                                     transport=args.transport)
+        lookups = []
+        for b in range(2):
+            ss.step(cbuf[b].data_ptr(), coff[b].data_ptr(), args.queries, sizes[b], ts, topn={})
+            lookups.append(ss.finish(ts)[0]["n_lookup"])
+        dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(n_batches):
+            ss.step(cbuf[i % 2].data_ptr(), coff[i % 2].data_ptr(), args.queries, sizes[i % 2], ts, topn={})
+        torch.cuda.synchronize()
+        dist.barrier()
+        dt = time.perf_counter() - t1
+        ss.finish(ts)
+        tt = torch.tensor([dt, float(sum(lookups[i % 2] for i in range(n_batches)))], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt[:1], op=dist.ReduceOp.MAX)
+        dist.all_reduce(tt[1:], op=dist.ReduceOp.SUM)   # every rank looks up only the keys its shard owns
+        rep = exchange_report(ss, ts, cbuf, coff, sizes)
+        rep.update({"ms_per_batch": float(tt[0]) / n_batches * 1e3, "lookups_per_s": float(tt[1]) / float(tt[0]),
+                    "query_seqs_per_s": args.queries * n_batches / float(tt[0]), "batches": n_batches, "scaling": "strong",
+                    "shard_build_s_rank0": build_s, "shard_keys_rank0": sst["n_keys"],
+                    "workload": "one common batch of %d %s searched by all %d ranks, each against its hash-prefix shard"
+                                % (args.queries, "reads" if nucl else "protein queries", world)})
+        ss.close()
+        six.close()
+        return rep
+
+    leg = None
+    if world > 1 and not sharded_mode and args.sharded_leg:
+        try:
+            leg = sharded_leg()
+        except Exception as e:   # the headline line must survive a failure of the secondary leg
+            leg = {"error": repr(e)}
+        log("sharded leg: %s" % json.dumps(leg))
 
     # work of the timed region = sum over the launches of their batch's exact counters
     n_timed = n_launch - first_timed
@@ -431,6 +537,10 @@ def main():
         "counters_per_batch_rank0": {k: round(v, 1) for k, v in c.items()},
         "roofline": roofline,
     }
+    if exch is not None:
+        out["exchange"] = exch
+    if leg is not None:
+        out["sharded_leg"] = leg
 
     if rank == 0:
         want_cpu = not args.no_cpu_baseline and world == 1 and not sharded_mode

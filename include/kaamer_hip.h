@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define KAAMER_ABI_VERSION 2
+#define KAAMER_ABI_VERSION 3
 #define KAAMER_KMER_SIZE 7 /* pkg/search/search.go:45, pkg/makedb/makedb.go:30 */
 
 typedef enum {
@@ -37,7 +37,8 @@ typedef enum {
     KAAMER_E_NOMEM = -3,     /* host or device allocation failed               */
     KAAMER_E_HIP = -4,       /* a HIP runtime call failed (no device, ...)     */
     KAAMER_E_CAPACITY = -5,  /* a workspace bound was exceeded; enlarge, retry */
-    KAAMER_E_FORMAT = -6     /* index image/version mismatch                   */
+    KAAMER_E_FORMAT = -6,    /* index image/version mismatch                   */
+    KAAMER_E_BUSY = -7       /* every host slot holds a batch: wait / pop first */
 } kaamer_status;
 
 /* search.go:41-44 */
@@ -184,7 +185,8 @@ typedef struct {
     uint64_t n_found;    /* lookups whose key is present                       */
     uint64_t n_post;     /* postings expanded = sum |index[key]| over found    */
     uint64_t n_hits;     /* (query, protein) result pairs                      */
-    uint64_t n_overflow; /* queries that left the on-chip counting tier        */
+    uint64_t n_overflow; /* queries counted by the G tier: a table beyond a   */
+                         /* wave's LDS arena, or more distinct hits than it    */
     uint64_t n_lists;    /* found lookups resolved through an arena list       */
                          /* (the others carry their single id in the slot)     */
     uint64_t n_list_ids; /* protein ids read from arena lists (<= n_post)      */
@@ -338,7 +340,8 @@ typedef struct {
     const uint64_t *top_off;        /* [n_reported + 1] CSR into the arrays    */
     const uint32_t *top_pid;
     const uint32_t *top_kmatch;
-    const uint32_t *top_first_pos;  /* relative to the untrimmed ORF           */
+    const uint32_t *top_first_pos;  /* relative to the untrimmed ORF; zeros for */
+                                    /* protein input (search.go:416)            */
     const uint8_t *orf_aa;          /* reported ORFs' residues, concatenated   */
     kaamer_counters counters;
 } kaamer_batch_top;
@@ -346,6 +349,30 @@ typedef struct {
 int kaamer_search_batch_top(kaamer_index *ix, const kaamer_batch_in *in, const kaamer_topn_opts *top,
                             kaamer_batch_top **out);
 void kaamer_batch_top_free(kaamer_batch_top *out);
+
+/* The same call in two halves, for callers that keep several batches in flight: the worker pool of
+ * search_protein.go:58-118 (N goroutines against shared read-only stores) becomes N callers against one index, each
+ * batch on a slot of its own (workspace, stream, pinned staging, result block; KAAMER_HOST_SLOTS of them, default 4).
+ * kaamer_search_batch_top is submit + wait and may be called from any number of threads concurrently.
+ *   submit  takes a free slot (blocks while all are busy), COPIES the caller's buffers (they are borrowed for the
+ *           call only), enqueues host-to-device copy, search, post-steps and ONE device-to-host copy of the packed
+ *           result, and returns;
+ *   wait    blocks until that batch is done, returns its result (free it with kaamer_batch_top_free) and releases the
+ *           slot and the ticket.  A ticket must be waited for exactly once, by any thread. */
+typedef struct kaamer_ticket kaamer_ticket;
+int kaamer_submit_batch_top(kaamer_index *ix, const kaamer_batch_in *in, const kaamer_topn_opts *top, kaamer_ticket **ticket);
+int kaamer_wait_batch_top(kaamer_ticket *ticket, kaamer_batch_top **out);
+
+/* Streaming (BASELINE configs[4]: reads streamed host -> GPU with double-buffered copies): a FIFO of batches with
+ * fixed options.  push copies chunk i + 1 and starts it while chunk i is still being searched; pop returns the
+ * oldest chunk's reported hits.  push returns KAAMER_E_BUSY instead of blocking when every slot holds one of this
+ * stream's own chunks: pop first.  One thread per stream; several streams may share an index. */
+typedef struct kaamer_stream kaamer_stream;
+int kaamer_stream_open(kaamer_index *ix, int32_t seq_type, const kaamer_topn_opts *top, kaamer_stream **out);
+int kaamer_stream_push(kaamer_stream *st, const uint8_t *seqs, const uint64_t *offsets, uint32_t n_seqs);
+int kaamer_stream_pop(kaamer_stream *st, kaamer_batch_top **out);
+uint32_t kaamer_stream_pending(const kaamer_stream *st);
+void kaamer_stream_close(kaamer_stream *st);
 
 /* ------------------------------------------------------------------------- */
 /* Sharded index, the exchange step as device code (no reference counterpart:  */

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # KAAMER_LIB points at an alternative build of the same library (tuning experiments only)
 LIB_PATH = os.environ.get("KAAMER_LIB") or os.path.join(_HERE, "libkaamer_hip.so")
 
-OK, E_ARG, E_IO, E_NOMEM, E_HIP, E_CAPACITY, E_FORMAT = 0, -1, -2, -3, -4, -5, -6
+OK, E_ARG, E_IO, E_NOMEM, E_HIP, E_CAPACITY, E_FORMAT, E_BUSY = 0, -1, -2, -3, -4, -5, -6, -7
 NUCLEOTIDE, PROTEIN, READS = 0, 1, 2
 
 
@@ -159,6 +159,13 @@ SYMBOLS = {
     "kaamer_topn_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "kaamer_search_batch_top": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "kaamer_batch_top_free": (None, [C.c_void_p]),
+    "kaamer_submit_batch_top": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "kaamer_wait_batch_top": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "kaamer_stream_open": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "kaamer_stream_push": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
+    "kaamer_stream_pop": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "kaamer_stream_pending": (C.c_uint32, [C.c_void_p]),
+    "kaamer_stream_close": (None, [C.c_void_p]),
     "kaamer_workspace_reset_timers": (None, [C.c_void_p]),
     "kaamer_workspace_set_timing": (None, [C.c_void_p, C.c_uint32]),
     "kaamer_filter_results": (C.c_int64, [C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_int64, C.c_int64]),

@@ -365,9 +365,83 @@ class Index:
         finally:
             abi.lib().kaamer_batch_top_free(out)
 
+    def submit_top(self, seqs=None, packed=None, seq_type=abi.PROTEIN, min_k_ratio=0.05, min_k_match=10, max_results=10):
+        """kaamer_submit_batch_top: the batch is copied and enqueued on a free slot; -> a ticket whose wait() returns
+        the TopResult.  Several tickets may be in flight; submit blocks while every slot is busy."""
+        buf, offs = packed if packed is not None else pack_sequences(seqs)
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        bi = abi.BatchIn(buf.ctypes.data if len(buf) else None, offs.ctypes.data, len(offs) - 1, seq_type, 0)
+        to = abi.TopnOpts(min_k_ratio, min_k_match, max_results, 0, None, None, 0, 0)
+        t = C.c_void_p()
+        abi.check(abi.lib().kaamer_submit_batch_top(self._h, C.byref(bi), C.byref(to), C.byref(t)))
+        return TopTicket(t)
+
+    def stream(self, seq_type=abi.READS, min_k_ratio=0.05, min_k_match=10, max_results=10):
+        return TopStream(self, seq_type, min_k_ratio, min_k_match, max_results)
+
     def close(self):
         if self._h:
             abi.lib().kaamer_index_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class TopTicket:
+    """one batch in flight (kaamer_ticket); wait() exactly once"""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def wait(self):
+        out = C.POINTER(abi.BatchTop)()
+        h, self._h = self._h, None
+        abi.check(abi.lib().kaamer_wait_batch_top(h, C.byref(out)))
+        try:
+            return TopResult(out)
+        finally:
+            abi.lib().kaamer_batch_top_free(out)
+
+
+class TopStream:
+    """kaamer_stream_*: a FIFO of batches with fixed options (push chunk i + 1 while chunk i is searched)"""
+
+    def __init__(self, index, seq_type, min_k_ratio, min_k_match, max_results):
+        to = abi.TopnOpts(min_k_ratio, min_k_match, max_results, 0, None, None, 0, 0)
+        h = C.c_void_p()
+        abi.check(abi.lib().kaamer_stream_open(index._h, seq_type, C.byref(to), C.byref(h)))
+        self._h, self.index = h, index
+
+    def push(self, buf, offs):
+        """-> False when every slot is busy with this stream's own chunks (pop first), True when the chunk was taken"""
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        rc = abi.lib().kaamer_stream_push(self._h, buf.ctypes.data if len(buf) else None, offs.ctypes.data, len(offs) - 1)
+        if rc == abi.E_BUSY:
+            return False
+        abi.check(rc)
+        return True
+
+    def pop(self):
+        out = C.POINTER(abi.BatchTop)()
+        abi.check(abi.lib().kaamer_stream_pop(self._h, C.byref(out)))
+        try:
+            return TopResult(out)
+        finally:
+            abi.lib().kaamer_batch_top_free(out)
+
+    @property
+    def pending(self):
+        return int(abi.lib().kaamer_stream_pending(self._h))
+
+    def close(self):
+        if self._h:
+            abi.lib().kaamer_stream_close(self._h)
             self._h = None
 
     def __del__(self):

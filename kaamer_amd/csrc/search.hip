@@ -39,6 +39,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -80,13 +81,36 @@ struct HostSlot {
     size_t seq_cap = 0, off_cap = 0;
 };
 
+// one in-flight call of the pipelined host-buffer boundary (host_top.hip.inc)
+struct TopSlot {
+    kaamer_workspace *ws = nullptr;
+    kaamer_workspace_opts opts{};
+    hipStream_t stream = nullptr;
+    uint8_t *d_seqs = nullptr;
+    uint64_t *d_off = nullptr;
+    size_t seq_cap = 0, off_cap = 0;
+    uint8_t *h_in = nullptr;   // pinned: the caller's sequences, then (8-byte aligned) its offsets
+    size_t h_in_cap = 0;
+    uint8_t *d_block = nullptr;
+    size_t d_block_cap = 0;
+    size_t guess = 1u << 16;   // bytes of the block copied before its size is known (adapts to the previous call)
+    bool busy = false;
+};
+#define KAAMER_MAX_HOST_SLOTS 8
+static void top_slot_free(TopSlot &h);
+
 struct kaamer_index {
     int device;
     kh_image_header hdr;
     kh_bucket *d_buckets;
     uint32_t *d_arena;
-    std::mutex host_mu;   // host-buffer calls on one index are serialised
-    HostSlot host[2];     // [0] kaamer_search_batch, [1] kaamer_search_batch_top
+    std::mutex host_mu;   // kaamer_search_batch (full hit lists) calls on one index are serialised
+    HostSlot host[1];     // its workspace and staging
+    // kaamer_submit_batch_top / kaamer_search_batch_top / kaamer_stream_*: a pool of slots, one per call in flight
+    std::mutex pool_mu;
+    std::condition_variable pool_cv;
+    TopSlot top[KAAMER_MAX_HOST_SLOTS];
+    int n_top;
 };
 
 enum { ST_POOL_FULL = 1u, ST_LIST_FULL = 2u, ST_QUERY_CAP = 4u, ST_AA_CAP = 8u, ST_G_ARENA_FULL = 16u, ST_G_TABLE_FULL = 32u,
@@ -100,7 +124,9 @@ enum { LIST_S = 0, LIST_L, LIST_SO, LIST_G, N_LISTS };
 // small per-batch device state after the list counters (all zeroed by the finalize step)
 enum { SLOT_QUEUE_HEAD = N_LISTS, SLOT_STATUS = N_LISTS + 1, SLOT_GROUP_QUEUE = N_LISTS + 2, SLOT_GROUP_QUEUE_POS = N_LISTS + 3,
        SLOT_N_LONG = N_LISTS + 4, SLOT_TILES_DONE = N_LISTS + 5, SLOT_TR_TICKET = N_LISTS + 6,
-       SLOT_QUEUE_SUB = N_LISTS + 7 /* 8 words */, SLOT_G_TICKET = N_LISTS + 15, N_SMALL_SLOTS = N_LISTS + 16 };
+       SLOT_QUEUE_SUB = N_LISTS + 7 /* 8 words */, SLOT_G_TICKET = N_LISTS + 15, SLOT_PACK_TICKETS = N_LISTS + 16 /* 64 words */,
+       N_SMALL_SLOTS = N_LISTS + 16 + 64 };
+static_assert(N_SMALL_SLOTS <= 256, "the finalize step zeroes one slot per thread");
 // one entry: everything a tier needs to start on a query, in one 16-byte load
 struct alignas(16) WorkItem {
     uint32_t q;
@@ -339,6 +365,8 @@ struct CountParams {
     const uint32_t *d_n_groups;
     const uint32_t *d_nq;
     uint32_t last_group_pass;   // this launch may clear group_first behind itself
+    uint32_t pack_shift;        // count_pack_kernel: a pack = the tables that start in one window of (1 << pack_shift) slots
+    uint32_t *pack_tickets;     // count_pack_kernel: PK_TICKETS counters, one per range of packs (zeroed by finalize)
     // PositionHits pass (count_group_kernel MODE 1)
     const uint64_t *pos_base;
     unsigned long long *pos_bits;
@@ -671,6 +699,9 @@ __device__ __forceinline__ void mark_invalid_range(unsigned long long *invalid, 
 }
 
 #include "count_group.hip.inc"
+#define PK_ARENA_PROT 1600u
+#define PK_ARENA_ORF 640u
+#include "count_pack.hip.inc"
 
 // ---- G tier: counting table in HBM, sized from the query's exact postings count -------------------
 struct NullTable {
@@ -723,7 +754,7 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
     // items (all but one when there are none) leave at once -- they take no part in the completion count either
     const uint32_t n_part = n_items < gridDim.x ? (n_items ? n_items : 1u) : gridDim.x;
     if (blockIdx.x >= n_part) return;
-    unsigned long long tot_hits = 0;
+    unsigned long long tot_hits = 0, f_post = 0, f_lists = 0, f_lids = 0;
     PostCtr pc;
     NullTable nt;
     nt.nd = &s_nd;
@@ -770,7 +801,10 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
     for (uint32_t item = blockIdx.x; item < n_items;) {
         const WorkItem wi = p.list[item];
         const uint32_t q = wi.q;
-        const int32_t size = wi.size;
+        // a negative size: the query was sent here unseen (its table does not fit a wave's arena, count_pack.hip.inc), so
+        // its postings have not been counted anywhere yet; otherwise it overflowed its table and they have
+        const bool fresh = wi.size < 0;
+        const int32_t size = fresh ? -wi.size : wi.size;
         const uint32_t *vals = p.vals + wi.aa_off;
         if (tid == 0) {
             s_nd = 0; s_fail = 0; s_post = 0; s_cursor = 0; s_long.n = 0;
@@ -785,6 +819,10 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
         {
             const unsigned long long wp = wave_total(pc.post);
             if (lane == 0 && wp) atomicAdd(&s_post, wp);
+            if (fresh) {
+                const uint32_t wl = wave_total(pc.lists), wi_ = wave_total(pc.lids);
+                if (lane == 0) { f_post += wp; f_lists += wl; f_lids += wi_; }
+            }
         }
         __syncthreads();
         // ---- first attempt: the whole query in the big LDS table
@@ -915,6 +953,9 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
     if (lane == 0) {
         const uint32_t rep = blockIdx.x * WAVES + wv;
         add_counter(p.counters, rep, CTR_HITS, tot_hits);
+        add_counter(p.counters, rep, CTR_POST, f_post);
+        add_counter(p.counters, rep, CTR_LISTS, f_lists);
+        add_counter(p.counters, rep, CTR_LIST_IDS, f_lids);
     }
     if (p.fin_out) {
         // the batch ends here: the last workgroup to arrive does the finalize step
@@ -978,7 +1019,7 @@ __global__ __launch_bounds__(64 * G_WAVES) void positions_global_kernel(CountPar
     for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
         const WorkItem wi = p.list[item];
         const uint32_t q = wi.q, cnt = p.q_cnt[q];
-        const int32_t size = wi.size;
+        const int32_t size = wi.size < 0 ? -wi.size : wi.size;  // (negative: sent to the G tier unseen, see count_global_kernel)
         const unsigned long long hoff = p.hit_off[q];
         uint32_t log2cap = 10;
         while ((1ull << log2cap) < 2ull * cnt && log2cap < 31) log2cap++;
@@ -1174,7 +1215,9 @@ struct kaamer_workspace {
     bool compact;                       // finish with CSR in query order (scan + gather pass)
     uint64_t *d_csr_off;                // compact form: CSR offsets
     uint32_t *d_c_pid, *d_c_km, *d_c_fp;
-    int g_grid, p_grid, n_cu;
+    int g_grid, p_grid, n_cu, pack_grid;
+    bool use_group;
+    uint32_t pack_shift;                // log2 of the pack window (slots) of a search: 8 for protein, 10 for ORF batches
     // device buffers
     kaamer_query_meta *d_q;
     uint32_t *d_nq;
@@ -1290,6 +1333,8 @@ int kaamer_index_open_image(const kaamer_image *img, int device, kaamer_index **
     kaamer_index *ix = new (std::nothrow) kaamer_index();
     if (!ix) return kaamer_fail(KAAMER_E_NOMEM, "index alloc");
     ix->device = device;
+    ix->n_top = 4;  // calls in flight through the host-buffer boundary
+    if (const char *e = getenv("KAAMER_HOST_SLOTS")) { const int v = atoi(e); if (v >= 1 && v <= KAAMER_MAX_HOST_SLOTS) ix->n_top = v; }
     ix->hdr = img->hdr;
     ix->d_buckets = nullptr;
     ix->d_arena = nullptr;
@@ -1298,6 +1343,9 @@ int kaamer_index_open_image(const kaamer_image *img, int device, kaamer_index **
     if (rc) { kaamer_index_close(ix); return rc; }
     hipError_t e = hipMemcpy(ix->d_buckets, img->buckets, (size_t)img->hdr.n_buckets * sizeof(kh_bucket), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(ix->d_arena, img->arena, (size_t)img->hdr.arena_words * 4, hipMemcpyHostToDevice);
+    // list offset 0 is never handed out (kaamer_layout.h) and reads as "no list": the counting kernel loads it for
+    // positions without a list instead of branching around the load (count_pack.hip.inc)
+    if (e == hipSuccess) e = hipMemset(ix->d_arena, 0, 16);
     if (e != hipSuccess) { kaamer_index_close(ix); return kaamer_fail(KAAMER_E_HIP, "index upload: %s", hipGetErrorString(e)); }
     *out = ix;
     return KAAMER_OK;
@@ -1322,6 +1370,7 @@ void kaamer_index_close(kaamer_index *ix)
         if (h.d_seqs) (void)hipFree(h.d_seqs);
         if (h.d_off) (void)hipFree(h.d_off);
     }
+    for (TopSlot &h : ix->top) top_slot_free(h);
     if (ix->d_buckets) (void)hipFree(ix->d_buckets);
     if (ix->d_arena) (void)hipFree(ix->d_arena);
     delete ix;
@@ -1415,11 +1464,32 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
         ws->g_grid = ws->n_cu * (g_per_cu > 2 ? 2 : g_per_cu);
     }
     ws->p_grid = ws->n_cu * p_per_cu;
+    {
+        int pk_per_cu = 0;
+        hipError_t ke = ws->nucleotide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&pk_per_cu, count_pack_kernel<true, PK_ARENA_ORF>, 64, 0)
+                        : ws->firstpos ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&pk_per_cu, count_pack_kernel<true, PK_ARENA_PROT>, 64, 0)
+                                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&pk_per_cu, count_pack_kernel<false, PK_ARENA_PROT>, 64, 0);
+        if (ke != hipSuccess || pk_per_cu < 1) pk_per_cu = 1;
+        if (const char *e = getenv("KAAMER_PACK_PER_CU")) { const int v = atoi(e); if (v >= 1 && v < pk_per_cu) pk_per_cu = v; }
+        ws->pack_grid = ws->n_cu * pk_per_cu;
+    }
+    // the pack window: a protein query's table is ~530 slots, so a window of 512 slots holds one or two table starts
+    // (tables up to PK_ARENA - 448 slots at full size); an ORF batch has tables of 64-128 slots: 8-16 ORFs to a pack
+    ws->pack_shift = 9u;
+    if (const char *e = getenv("KAAMER_PACK_SHIFT")) { const int v = atoi(e); if (v >= 8 && v <= 10) ws->pack_shift = (uint32_t)v; }
+    // Which counting kernel: ORF batches (tables of 64-128 slots, 24 one-wave workgroups per CU) take the pack kernel;
+    // protein batches the group kernel -- a wave alone on a 700-position query is a 50 us critical path, and with the
+    // 11 waves per CU a protein arena allows the pack kernel took 117-156 us against the group kernel's 100
+    // (profiles/r03_count_kernels.md).  KAAMER_COUNT_GROUP / KAAMER_COUNT_PACK force one or the other (A/B runs).
+    ws->use_group = !ws->nucleotide;
+    if (getenv("KAAMER_COUNT_GROUP")) ws->use_group = true;
+    if (getenv("KAAMER_COUNT_PACK")) ws->use_group = false;
+    if (ws->use_group) ws->pack_shift = GRP_SHIFT;
     // a table has at most max(64, 3 x SizeInKmer) slots
     {
         // (a merge counts partial entries instead of positions: as many as max_hits)
         const uint64_t items = ws->pos_cap > ws->hit_cap ? ws->pos_cap : ws->hit_cap;
-        const uint64_t gc = ((uint64_t)GRP_MIN_TABLE * ws->q_cap + 3 * items) / GRP_BUDGET + 4;
+        const uint64_t gc = (((uint64_t)GRP_MIN_TABLE * ws->q_cap + 3 * items) >> 8) + 4;  // windows of 256 slots at the least
         ws->groups_cap = (uint32_t)(gc > 0x7FFFFFFFull ? 0x7FFFFFFFull : gc);
     }
     int rc = KAAMER_OK;
@@ -1509,15 +1579,17 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
 }
 
 // table layout + query groups (count_group.hip.inc): one single-pass kernel
-static void launch_layout(kaamer_workspace *ws, uint32_t nq_bound, uint32_t *status, hipStream_t s)
+static void launch_layout(kaamer_workspace *ws, uint32_t nq_bound, uint32_t *status, hipStream_t s, uint32_t bshift, bool schedule = true)
 {
+    const uint32_t cshift = bshift >= GRP_SHIFT ? 9u : 7u;  // 16 schedule classes over the slots a group / pack can hold
     ws->lay_epoch = (ws->lay_epoch + 1u) & 0xFFFFFFu;
     if (ws->lay_epoch == 0) ws->lay_epoch = 1;
     const uint32_t tiles = (uint32_t)(((uint64_t)nq_bound + 1 + LAY_TILE - 1) / LAY_TILE);
     hipLaunchKernelGGL(layout_kernel, dim3(tiles), dim3(LAY_THREADS), 0, s, ws->d_slots, ws->d_nq, ws->d_slot_off, ws->d_group_first,
-                       ws->d_group_start, ws->d_n_groups, ws->groups_cap, ws->d_chain, ws->lay_epoch, status);
-    hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(1024), 0, s, ws->d_group_first, ws->d_group_start, ws->d_slot_off, ws->d_n_groups,
-                       ws->d_nq, ws->d_sched, ws->d_n_sched);
+                       ws->d_group_start, ws->d_n_groups, ws->groups_cap, ws->d_chain, ws->lay_epoch, status, bshift);
+    if (schedule)  // (the pack kernel takes its packs by ticket in layout order: no schedule)
+        hipLaunchKernelGGL(schedule_kernel, dim3(1), dim3(1024), 0, s, ws->d_group_first, ws->d_group_start, ws->d_slot_off, ws->d_n_groups,
+                           ws->d_nq, ws->d_sched, ws->d_n_sched, cshift);
 }
 
 // optional last step of a search / merge: CSR in query order from the sharded hit arrays
@@ -1605,6 +1677,8 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         pl.epoch = ws->lay_epoch;
         pl.status = status; pl.sched = ws->d_sched; pl.d_n_sched = ws->d_n_sched;
         pl.tiles_done = ws->d_list_counts + SLOT_TILES_DONE;
+        pl.slots = ws->d_slots; pl.bshift = ws->pack_shift; pl.cshift = ws->pack_shift >= GRP_SHIFT ? 9u : 7u;
+        pl.no_sched = ws->use_group ? 0u : 1u;
         pl.d_total = ws->d_lay_total;
         const uint32_t tiles = (uint32_t)(((uint64_t)n_seqs + 1 + PL_TILE - 1) / PL_TILE);
         hipLaunchKernelGGL(prep_layout_schedule_kernel, dim3(tiles), dim3(LAY_THREADS), 0, s, pl);
@@ -1672,7 +1746,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     }
 
     // ---- query groups: table layout, first query of each group, schedule (protein: done with the prep)
-    if (nucl) launch_layout(ws, nq_bound, status, s);
+    if (nucl) launch_layout(ws, nq_bound, status, s, ws->pack_shift, ws->use_group);
 
     // ---- kernel P: flat probe
     ProbeParams pp;
@@ -1726,13 +1800,19 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     CountParams pc = p;
     pc.ovf_list = list_ptr(LIST_G); pc.ovf_count = ws->d_list_counts + LIST_G;
     pc.last_group_pass = ws->want_positions ? 0u : 1u;
-    uint64_t grp_blocks = 1;
+    pc.pack_shift = ws->pack_shift;
+    pc.pack_tickets = ws->d_list_counts + SLOT_PACK_TICKETS;
     {
-        // at most one workgroup per group; groups <= slots / GRP_BUDGET
-        uint64_t gb = ((uint64_t)GRP_MIN_TABLE * nq_bound + 3 * pos_bound) / GRP_BUDGET + 1;
-        if (gb > (uint64_t)ws->grp_grid) gb = ws->grp_grid;
-        grp_blocks = gb;
-        launch_group(pc, (int)gb, ws->firstpos, s);
+        // one wave per workgroup, packs dealt out statically: never more waves than packs
+        uint64_t gb = (((uint64_t)GRP_MIN_TABLE * nq_bound + 3 * pos_bound) >> ws->pack_shift) + 1;
+        if (gb > (uint64_t)ws->pack_grid) gb = ws->pack_grid;
+        if (ws->use_group) {
+            uint64_t gg = ((uint64_t)GRP_MIN_TABLE * nq_bound + 3 * pos_bound) / GRP_BUDGET + 1;
+            if (gg > (uint64_t)ws->grp_grid) gg = ws->grp_grid;
+            launch_group(pc, (int)gg, ws->firstpos, s);
+        } else if (ws->nucleotide) hipLaunchKernelGGL((count_pack_kernel<true, PK_ARENA_ORF>), dim3((unsigned)gb), dim3(64), 0, s, pc);
+        else if (ws->firstpos) hipLaunchKernelGGL((count_pack_kernel<true, PK_ARENA_PROT>), dim3((unsigned)gb), dim3(64), 0, s, pc);
+        else hipLaunchKernelGGL((count_pack_kernel<false, PK_ARENA_PROT>), dim3((unsigned)gb), dim3(64), 0, s, pc);
     }
     CountParams pg = p;
     pg.list = list_ptr(LIST_G); pg.list_count = ws->d_list_counts + LIST_G;
@@ -1765,6 +1845,10 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         hipLaunchKernelGGL(pos_layout_kernel, dim3(ws->n_cu * 8), dim3(256), 0, s, ws->d_qinfo, ws->d_q_cnt,
                            ws->compact ? ws->d_csr_off : ws->d_hit_off,
                            ws->d_pos_base, ws->d_nq, ws->d_pos_off, ws->d_pos_bits, ws->bits_cap, status);
+        // the PositionHits pass runs on the group kernel: lay the tables out in its groups
+        launch_layout(ws, nq_bound, status, s, GRP_SHIFT);
+        uint64_t grp_blocks = ((uint64_t)GRP_MIN_TABLE * nq_bound + 3 * pos_bound) / GRP_BUDGET + 1;
+        if (grp_blocks > (uint64_t)ws->grp_grid) grp_blocks = ws->grp_grid;
         CountParams pp2 = p;
         pp2.last_group_pass = 1u;
         pp2.pos_base = ws->d_pos_base;
@@ -1824,7 +1908,7 @@ static int merge_device_impl(kaamer_workspace *ws, const uint64_t *d_ent_off, co
     const int pb = 256;
     hipLaunchKernelGGL(prep_merge_kernel, dim3((n_queries + pb - 1) / pb > 0 ? (n_queries + pb - 1) / pb : 1), dim3(pb), 0, s, d_ent_off,
                        n_queries, d_n_queries, ws->d_qinfo, ws->d_slots, ws->d_nq, ws->d_hit_off, ws->d_q_cnt);
-    launch_layout(ws, nq_bound, status, s);
+    launch_layout(ws, nq_bound, status, s, GRP_SHIFT);
     CountParams p;
     memset(&p, 0, sizeof p);
     p.qinfo = ws->d_qinfo;
@@ -2361,188 +2445,7 @@ int kaamer_search_batch(kaamer_index *ix, const kaamer_batch_in *in, kaamer_batc
     }
 }
 
-// ---- host-buffer form that returns what a caller reports: the filtered top hits only ----------
-struct batch_top_owner {
-    kaamer_batch_top pub;
-    std::vector<uint32_t> rep_query;
-    std::vector<kaamer_query_meta> q;
-    std::vector<int32_t> trim;
-    std::vector<uint64_t> off;
-    std::vector<uint32_t> pid, km, fp;
-    std::vector<uint8_t> orf_aa;
-};
-
-static void scan_u32_on(kaamer_workspace *ws, const uint32_t *cnt, const uint32_t *d_count, uint64_t bound, uint64_t *off, hipStream_t s)
-{
-    if (bound <= 8 * (uint64_t)SCAN_TILE) {
-        hipLaunchKernelGGL(scan_single_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, cnt, d_count, off);
-    } else {
-        const uint32_t nsb = (uint32_t)((bound + 1 + SCAN_TILE - 1) / SCAN_TILE);
-        hipLaunchKernelGGL(scan_block_sums_kernel, dim3(nsb), dim3(SCAN_BLOCK), 0, s, cnt, d_count, ws->d_bsum);
-        hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, ws->d_bsum, nsb);
-        hipLaunchKernelGGL(scan_apply_kernel, dim3(nsb), dim3(SCAN_BLOCK), 0, s, cnt, d_count, ws->d_bsum, off);
-    }
-}
-
-// packs the reported queries of the last kaamer_topn_device call (topn.hip.inc)
-static int topn_pack_reported(kaamer_workspace *ws, const kaamer_topn_result *tr, bool nucl, hipStream_t s, RepParams *rp)
-{
-    if (ws->rep_k < tr->max_results) {
-        uint32_t **bufs[] = { &ws->d_rep_pid, &ws->d_rep_km, &ws->d_rep_fp };
-        for (uint32_t **b : bufs) { if (*b) (void)hipFree(*b); *b = nullptr; }
-        const size_t n = (size_t)ws->q_cap * tr->max_results;
-        int rc = dev_alloc(&ws->d_rep_pid, n);
-        if (!rc) rc = dev_alloc(&ws->d_rep_km, n);
-        if (!rc) rc = dev_alloc(&ws->d_rep_fp, n);
-        if (!rc && !ws->d_rep_flag) {
-            rc = dev_alloc(&ws->d_rep_flag, ws->q_cap);
-            if (!rc) rc = dev_alloc(&ws->d_rep_aalen, ws->q_cap);
-            if (!rc) rc = dev_alloc(&ws->d_rep_query, ws->q_cap);
-            if (!rc) rc = dev_alloc(&ws->d_rep_trim, ws->q_cap);
-            if (!rc) rc = dev_alloc(&ws->d_rep_rank, (size_t)ws->q_cap + 1);
-            if (!rc) rc = dev_alloc(&ws->d_rep_eoff, (size_t)ws->q_cap + 1);
-            if (!rc) rc = dev_alloc(&ws->d_rep_aoff, (size_t)ws->q_cap + 1);
-            if (!rc) rc = dev_alloc(&ws->d_rep_off, (size_t)ws->q_cap + 1);
-            if (!rc) rc = dev_alloc(&ws->d_rep_q, ws->q_cap);
-            if (!rc && ws->nucleotide) rc = dev_alloc(&ws->d_rep_aa, (size_t)ws->aa_cap + 64);
-        }
-        if (rc) { ws->rep_k = 0; return rc; }
-        ws->rep_k = tr->max_results;
-    }
-    RepParams p;
-    memset(&p, 0, sizeof p);
-    p.d_nq = ws->d_nq; p.q = ws->d_q; p.top_cnt = tr->d_top_cnt;
-    p.trim = tr->d_trim; p.start_pos = tr->d_start_position; p.size_out = tr->d_size_in_kmer;
-    p.K = tr->max_results;
-    p.top_pid = tr->d_top_pid; p.top_km = tr->d_top_kmatch; p.top_fp = tr->d_top_first_pos;
-    p.orf_aa = nucl ? ws->d_orf_aa : nullptr;
-    p.flag = ws->d_rep_flag; p.aalen = ws->d_rep_aalen;
-    p.rank = ws->d_rep_rank; p.eoff = ws->d_rep_eoff; p.aoff = ws->d_rep_aoff;
-    p.rep_query = ws->d_rep_query; p.rep_q = ws->d_rep_q; p.rep_trim = ws->d_rep_trim; p.rep_off = ws->d_rep_off;
-    p.rep_pid = ws->d_rep_pid; p.rep_km = ws->d_rep_km; p.rep_fp = ws->d_rep_fp; p.rep_aa = ws->d_rep_aa;
-    const uint64_t bound = ws->q_cap;
-    hipLaunchKernelGGL(rep_flags_kernel, dim3(ws->n_cu * 4), dim3(256), 0, s, p);
-    scan_u32_on(ws, ws->d_rep_flag, ws->d_nq, bound, ws->d_rep_rank, s);
-    scan_u32_on(ws, tr->d_top_cnt, ws->d_nq, bound, ws->d_rep_eoff, s);
-    scan_u32_on(ws, ws->d_rep_aalen, ws->d_nq, bound, ws->d_rep_aoff, s);
-    hipLaunchKernelGGL(rep_gather_kernel, dim3(ws->n_cu * 8), dim3(256), 0, s, p);
-    HIPCHK(hipGetLastError());
-    *rp = p;
-    return KAAMER_OK;
-}
-
-static int search_batch_top_once(kaamer_index *ix, const kaamer_batch_in *in, const kaamer_topn_opts *top, uint64_t max_hits,
-                                 uint64_t g_slots, uint32_t max_queries, kaamer_batch_top **out)
-{
-    const uint64_t seq_bytes = in->offsets[in->n_seqs];
-    const bool nucl = in->seq_type == KAAMER_NUCLEOTIDE || in->seq_type == KAAMER_READS;
-    kaamer_workspace_opts o;
-    memset(&o, 0, sizeof o);
-    o.max_seq_bytes = seq_bytes;
-    o.max_seqs = in->n_seqs ? in->n_seqs : 1;
-    o.max_hits = max_hits;
-    o.g_tier_slots = g_slots;
-    o.seq_type = in->seq_type;
-    o.first_pos = 1;
-    o.max_queries = max_queries;
-    HostSlot &slot = ix->host[1];
-    int rc = host_slot_acquire(ix, slot, o, seq_bytes, in->n_seqs);
-    if (rc) return rc;
-    kaamer_workspace *ws = slot.ws;
-    uint8_t *d_seqs = slot.d_seqs;
-    uint64_t *d_off = slot.d_off;
-    batch_top_owner *bo = nullptr;
-    hipStream_t s = nullptr;
-    kaamer_device_result dr;
-    kaamer_topn_result tr;
-    kaamer_topn_opts t = *top;
-    RepParams rp;
-    kaamer_counters c;
-    uint32_t nq = 0;
-    uint64_t n_rep = 0, n_ent = 0, n_aa = 0;
-    hipError_t e;
-    t.best_start_codon = nucl ? 1u : 0u;  // search_fastq.go:121, search_nucleotide.go:118; not in search_protein.go
-    t.d_size_in_kmer = nullptr;
-    e = hipMemcpyAsync(d_seqs, in->seqs, (size_t)seq_bytes, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_off, in->offsets, ((size_t)in->n_seqs + 1) * 8, hipMemcpyHostToDevice, s);
-    if (e != hipSuccess) { rc = kaamer_fail(KAAMER_E_HIP, "H2D: %s", hipGetErrorString(e)); goto done; }
-    rc = kaamer_search_device(ix, ws, d_seqs, d_off, in->n_seqs, seq_bytes, in->seq_type, s, &dr);
-    if (!rc) rc = kaamer_topn_device(ws, &t, s, &tr);
-    if (!rc) rc = topn_pack_reported(ws, &tr, nucl, s, &rp);
-    if (!rc) rc = kaamer_workspace_finish(ws, s, &c);
-    if (rc) goto done;
-    bo = new (std::nothrow) batch_top_owner();
-    if (!bo) { rc = kaamer_fail(KAAMER_E_NOMEM, "batch_top"); goto done; }
-    e = hipMemcpy(&nq, dr.d_n_queries, 4, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(&n_rep, rp.rank + nq, 8, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(&n_ent, rp.eoff + nq, 8, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(&n_aa, rp.aoff + nq, 8, hipMemcpyDeviceToHost);
-    if (e == hipSuccess) {
-        bo->rep_query.resize(n_rep + 1); bo->q.resize(n_rep + 1); bo->trim.resize(n_rep + 1); bo->off.resize(n_rep + 1);
-        bo->pid.resize(n_ent + 1); bo->km.resize(n_ent + 1); bo->fp.resize(n_ent + 1);
-        bo->orf_aa.resize(n_aa + 1);
-        bo->off[n_rep] = 0;
-        if (n_rep) {
-            e = hipMemcpy(bo->rep_query.data(), rp.rep_query, n_rep * 4, hipMemcpyDeviceToHost);
-            if (e == hipSuccess) e = hipMemcpy(bo->q.data(), rp.rep_q, n_rep * sizeof(kaamer_query_meta), hipMemcpyDeviceToHost);
-            if (e == hipSuccess) e = hipMemcpy(bo->trim.data(), rp.rep_trim, n_rep * 4, hipMemcpyDeviceToHost);
-        }
-        if (e == hipSuccess) e = hipMemcpy(bo->off.data(), rp.rep_off, (n_rep + 1) * 8, hipMemcpyDeviceToHost);
-        if (e == hipSuccess && n_ent) {
-            e = hipMemcpy(bo->pid.data(), rp.rep_pid, n_ent * 4, hipMemcpyDeviceToHost);
-            if (e == hipSuccess) e = hipMemcpy(bo->km.data(), rp.rep_km, n_ent * 4, hipMemcpyDeviceToHost);
-            if (e == hipSuccess) e = hipMemcpy(bo->fp.data(), rp.rep_fp, n_ent * 4, hipMemcpyDeviceToHost);
-        }
-        if (e == hipSuccess && n_aa) e = hipMemcpy(bo->orf_aa.data(), rp.rep_aa, n_aa, hipMemcpyDeviceToHost);
-    }
-    if (e != hipSuccess) { rc = kaamer_fail(KAAMER_E_HIP, "D2H: %s", hipGetErrorString(e)); goto done; }
-    memset(&bo->pub, 0, sizeof bo->pub);
-    bo->pub.n_queries = nq;
-    bo->pub.n_reported = (uint32_t)n_rep;
-    bo->pub.max_results = t.max_results;
-    bo->pub.rep_query = bo->rep_query.data();
-    bo->pub.q = bo->q.data();
-    bo->pub.trim = bo->trim.data();
-    bo->pub.top_off = bo->off.data();
-    bo->pub.top_pid = bo->pid.data();
-    bo->pub.top_kmatch = bo->km.data();
-    bo->pub.top_first_pos = bo->fp.data();
-    if (nucl) bo->pub.orf_aa = bo->orf_aa.data();
-    bo->pub.counters = c;
-    *out = &bo->pub;
-    bo = nullptr;
-done:
-    delete bo;
-    return rc;
-}
-
-int kaamer_search_batch_top(kaamer_index *ix, const kaamer_batch_in *in, const kaamer_topn_opts *top, kaamer_batch_top **out)
-{
-    if (!ix || !in || !top || !out || !in->offsets || (in->n_seqs && !in->seqs) || top->max_results < 1)
-        return kaamer_fail(KAAMER_E_ARG, "search_batch_top: bad argument");
-    *out = nullptr;
-    std::lock_guard<std::mutex> lock(ix->host_mu);
-    HIPCHK(hipSetDevice(ix->device));
-    uint64_t max_hits = 0, g_slots = 0;  // the device form derives the hit arrays from the batch size; only the G tier can run out
-    uint32_t max_queries = 0;
-    const bool nucl = in->seq_type == KAAMER_NUCLEOTIDE || in->seq_type == KAAMER_READS;
-    for (int attempt = 0;; attempt++) {
-        const int rc = search_batch_top_once(ix, in, top, max_hits, g_slots, max_queries, out);
-        if (rc != KAAMER_E_CAPACITY || attempt >= 6) return rc;
-        max_hits = max_hits ? max_hits * 4 : in->offsets[in->n_seqs] * 8 + 65536;
-        g_slots = g_slots ? g_slots * 4 : (128ull << 20);
-        if (nucl) {
-            const uint64_t hard = in->offsets[in->n_seqs] / 10 + (uint64_t)in->n_seqs * 6 + 64;
-            max_queries = (uint32_t)(hard > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : hard);
-        }
-    }
-}
-
-void kaamer_batch_top_free(kaamer_batch_top *out)
-{
-    if (!out) return;
-    delete reinterpret_cast<batch_top_owner *>(out);  // pub is the first member
-}
+#include "host_top.hip.inc"
 
 void kaamer_batch_free(kaamer_batch_out *out)
 {

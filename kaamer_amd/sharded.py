@@ -117,6 +117,7 @@ class ShardedSearcher:
         if first_pos is None:
             first_pos = self.nucl
         fp = 1 if first_pos else 2
+        self.ws_first_pos = bool(first_pos)
         self.ws = api.Workspace(index, max_seq_bytes, max_seqs, seq_type=seq_type, first_pos=fp, max_hits=max_hits,
                                 g_tier_slots=g_tier_slots)
         self.layout = abi.ExchangeLayout()

@@ -1,13 +1,12 @@
 """Host-resident batches larger than one device batch (BASELINE configs[4]: reads streamed
 host -> GPU with double-buffered asynchronous copies).  The packed reads are cut into chunks of
-whole sequences; chunk i+1 is copied to the device (pinned staging buffer, its own stream) while
-chunk i is searched, and only what a caller reports comes back: per ORF the hits that survive the
-device post-steps (kaamer_topn_device).  Plumbing only: PyTorch owns the pinned and device buffers
-and the streams; the search is the C-ABI device call."""
+whole sequences and pushed through the library's streaming entry points (kaamer_stream_open /
+_push / _pop, include/kaamer_hip.h): chunk i + 1 is copied into pinned staging and on to the device
+while chunk i is searched, and only what a caller reports comes back -- per ORF the hits that survive
+the device post-steps.  This module is a thin ctypes caller: chunking and result bookkeeping only."""
 import numpy as np
-import torch
 
-from . import abi, api
+from . import abi
 
 
 def chunk_bounds(offsets, max_seqs, max_bytes):
@@ -29,68 +28,38 @@ def chunk_bounds(offsets, max_seqs, max_bytes):
 class StreamingSearcher:
     def __init__(self, index, max_chunk_seqs, max_chunk_bytes, seq_type=abi.READS, n_buffers=2,
                  min_k_ratio=0.05, min_k_match=10, max_results=10):
+        """n_buffers: chunks kept in flight (the library holds KAAMER_HOST_SLOTS slots, default 4)"""
         self.index, self.seq_type = index, seq_type
         self.max_seqs, self.max_bytes, self.k = max_chunk_seqs, max_chunk_bytes, max_results
-        self.opts = (min_k_ratio, min_k_match, max_results)
-        self.nucl = seq_type in (abi.READS, abi.NUCLEOTIDE)
-        self.slots = []
-        for _ in range(n_buffers):
-            ws = api.Workspace(index, max_chunk_bytes, max_chunk_seqs, seq_type=seq_type,
-                               first_pos=0 if self.nucl else 2)
-            self.slots.append(dict(
-                ws=ws, stream=torch.cuda.Stream(),
-                h_buf=torch.empty(max_chunk_bytes + 16, dtype=torch.uint8).pin_memory(),
-                h_off=torch.empty(max_chunk_seqs + 1, dtype=torch.int64).pin_memory(),
-                d_buf=torch.empty(max_chunk_bytes + 16, dtype=torch.uint8, device="cuda"),
-                d_off=torch.empty(max_chunk_seqs + 1, dtype=torch.int64, device="cuda"),
-                busy=None))
+        self.n_buffers = max(1, n_buffers)
+        self.stream = index.stream(seq_type, min_k_ratio, min_k_match, max_results)
 
     def run(self, buf, offsets, on_chunk=None):
-        """Search every sequence of the packed host batch; `on_chunk(first_seq, n_seqs, counters,
-        top_cnt, rows, top_pid, top_kmatch)` receives host arrays per chunk: top_cnt for every ORF of
-        the chunk (input order), and for the reported ORFs only (`rows` = their indices, top_cnt > 0)
-        their max_results-wide rows of protein ids and Kmatch.  Returns the summed counters."""
+        """Search every sequence of the packed host batch; `on_chunk(first_seq, n_seqs, top)` receives each chunk's
+        api.TopResult (reported ORFs only, in input order).  Returns the summed counters."""
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         total = {}
-        pending = []
+        fifo = []
 
-        def drain(item):
-            slot, a, b, top = item
-            with torch.cuda.stream(slot["stream"]):
-                c = slot["ws"].finish(slot["stream"].cuda_stream)
-                nq = c["n_queries"]
-                if on_chunk is not None:
-                    from .sharded import dev_tensor
-                    d_cnt = dev_tensor(top.d_top_cnt, max(nq, 1), torch.int32)[:nq]
-                    rows = torch.nonzero(d_cnt > 0).flatten()      # only the reported ORFs cross PCIe
-                    d_pid = dev_tensor(top.d_top_pid, max(nq * self.k, 1), torch.int32)[:nq * self.k].view(nq, self.k)
-                    d_km = dev_tensor(top.d_top_kmatch, max(nq * self.k, 1), torch.int32)[:nq * self.k].view(nq, self.k)
-                    on_chunk(a, b - a, c, d_cnt.cpu().numpy().view(np.uint32), rows.cpu().numpy(),
-                             d_pid[rows].cpu().numpy().view(np.uint32), d_km[rows].cpu().numpy().view(np.uint32))
-            for k_, v in c.items():
+        def pop():
+            a, b = fifo.pop(0)
+            top = self.stream.pop()
+            if on_chunk is not None:
+                on_chunk(a, b - a, top)
+            for k_, v in top.counters.items():
                 total[k_] = total.get(k_, 0) + v
 
-        for i, (a, b) in enumerate(chunk_bounds(offsets, self.max_seqs, self.max_bytes)):
-            slot = self.slots[i % len(self.slots)]
-            if slot["busy"] is not None:      # the buffer's previous chunk must be done before it is overwritten
-                drain(slot["busy"])
-                pending.remove(slot["busy"])
-                slot["busy"] = None
+        for a, b in chunk_bounds(offsets, self.max_seqs, self.max_bytes):
             lo, hi = int(offsets[a]), int(offsets[b])
-            n, nbytes = b - a, hi - lo
-            slot["h_buf"][:nbytes].numpy()[:] = buf[lo:hi]                       # host memcpy into pinned memory
-            slot["h_off"][:n + 1].numpy()[:] = (offsets[a:b + 1] - offsets[a]).view(np.int64)
-            with torch.cuda.stream(slot["stream"]):
-                slot["d_buf"][:nbytes].copy_(slot["h_buf"][:nbytes], non_blocking=True)
-                slot["d_off"][:n + 1].copy_(slot["h_off"][:n + 1], non_blocking=True)
-                st = slot["stream"].cuda_stream
-                slot["ws"].search_device(slot["d_buf"].data_ptr(), slot["d_off"].data_ptr(), n, nbytes, stream=st)
-                top = slot["ws"].topn_device(*self.opts, best_start_codon=self.nucl, stream=st)
-            item = (slot, a, b, top)
-            slot["busy"] = item
-            pending.append(item)
-        for item in list(pending):
-            drain(item)
-            item[0]["busy"] = None
+            while len(fifo) >= self.n_buffers:
+                pop()
+            while not self.stream.push(buf[lo:hi], offsets[a:b + 1] - offsets[a]):
+                pop()   # every slot of the library is busy with our own chunks
+            fifo.append((a, b))
+        while fifo:
+            pop()
         return total
+
+    def close(self):
+        self.stream.close()

@@ -44,7 +44,7 @@ def test_dbsp_protein_queries(dbsp, oracle):
         assert res.hits(i) == exp, "query %d" % i
         assert res.first_pos(i) == expfp, "query %d" % i
         n_hits += len(exp)
-    assert n_hits > 50000 and res.counters["n_overflow"] == 0
+    assert n_hits > 50000 and res.counters["n_overflow"] <= 50   # queries counted by the G tier (with the pack kernel: tables beyond a wave's arena)
 
 
 def _oracle_report(oracle, oix, orf, min_k_ratio=0.05, min_k_match=10, max_results=10):
@@ -97,12 +97,9 @@ def test_dbsp_qmix_streamed(dbsp, oracle):
     assert (lens > 2000).sum() >= 20 and set(np.unique(lens[lens <= 250]).tolist()) == {100, 150, 250}
     got = []
 
-    def on_chunk(first, n, counters, cnt, rows, pid_rows, km_rows):
-        pid = np.zeros((len(cnt), 10), np.uint32)
-        km = np.zeros((len(cnt), 10), np.uint32)
-        pid[rows] = pid_rows
-        km[rows] = km_rows
-        got.append((cnt.copy(), pid, km))
+    def on_chunk(first, n, top):   # top: the chunk's api.TopResult, straight from kaamer_stream_pop
+        pid, km = top.dense()
+        got.append((top.top_cnt.copy(), pid, km))
 
     s = stream.StreamingSearcher(ix, max_chunk_seqs=200, max_chunk_bytes=96 * 1024)
     total = s.run(buf, offs, on_chunk)

@@ -24,20 +24,86 @@ def test_streamed_reads_equal_one_batch(klib, gpu_device):
     ref = ix.search_top(packed=reads, seq_type=abi.READS)
     got_cnt, got_pid, got_km = [], [], []
 
-    def on_chunk(first, n, counters, cnt, rows, pid_rows, km_rows):
-        pid = np.zeros((len(cnt), 10), np.uint32); km = np.zeros((len(cnt), 10), np.uint32)
-        assert (cnt[rows] > 0).all() and len(rows) == int((cnt > 0).sum())
-        pid[rows] = pid_rows; km[rows] = km_rows
-        got_cnt.append(cnt.copy()); got_pid.append(pid); got_km.append(km)
+    def on_chunk(first, n, top):
+        pid, km = top.dense()
+        assert top.n_reported == int((top.top_cnt > 0).sum())
+        got_cnt.append(top.top_cnt.copy()); got_pid.append(pid); got_km.append(km)
 
-    s = stream.StreamingSearcher(ix, max_chunk_seqs=700, max_chunk_bytes=64 * 1024)
-    total = s.run(buf, offs, on_chunk)
-    assert len(got_cnt) >= 5                                       # several chunks, both buffers reused
-    cnt = np.concatenate(got_cnt); pid = np.concatenate(got_pid); km = np.concatenate(got_km)
-    assert total["n_queries"] == ref.n_queries == len(cnt)
-    assert total["n_lookup"] == ref.counters["n_lookup"] and total["n_hits"] == ref.counters["n_hits"]
-    assert (cnt == ref.top_cnt).all()
-    rpid, rkm = ref.dense()
-    for q in range(ref.n_queries):
-        k = int(cnt[q])
-        assert pid[q, :k].tolist() == rpid[q, :k].tolist() and km[q, :k].tolist() == rkm[q, :k].tolist()
+    for n_buf in (1, 3, 6):   # 6 > the library's slots: push reports busy and the driver pops first
+        got_cnt, got_pid, got_km = [], [], []
+        s = stream.StreamingSearcher(ix, max_chunk_seqs=700, max_chunk_bytes=64 * 1024, n_buffers=n_buf)
+        total = s.run(buf, offs, on_chunk)
+        s.close()
+        assert len(got_cnt) >= 5                                       # several chunks, the slots reused
+        cnt = np.concatenate(got_cnt); pid = np.concatenate(got_pid); km = np.concatenate(got_km)
+        assert total["n_queries"] == ref.n_queries == len(cnt)
+        assert total["n_lookup"] == ref.counters["n_lookup"] and total["n_hits"] == ref.counters["n_hits"]
+        assert (cnt == ref.top_cnt).all()
+        rpid, rkm = ref.dense()
+        for q in range(ref.n_queries):
+            k = int(cnt[q])
+            assert pid[q, :k].tolist() == rpid[q, :k].tolist() and km[q, :k].tolist() == rkm[q, :k].tolist()
+
+
+@pytest.mark.gpu
+def test_concurrent_callers_and_tickets(klib, oracle, gpu_device):
+    """the worker pool of search_protein.go:58-118 against one index: N threads call kaamer_search_batch_top at once
+    (each on a slot of its own), and one thread keeps several tickets in flight; every result vs the oracle"""
+    import threading
+    from kaamer_amd import abi, api, workload
+    db = workload.make_db(1500, seed=4)
+    ix = api.Index.from_image(api.Image.from_proteins(packed=db), gpu_device)
+    oix = oracle.Index.from_proteins(None, packed=db)
+    batches = [workload.make_protein_queries(db, 60 + 7 * i, seed=20 + i) for i in range(6)] + \
+              [workload.make_reads(db, 150 + 10 * i, seed=40 + i) for i in range(3)]
+    kinds = [abi.PROTEIN] * 6 + [abi.READS] * 3
+
+    def expected(q, kind):
+        out = []
+        for s in workload.unpack(q):
+            items = [dict(seq=s)] if kind == abi.PROTEIN else oracle.get_orfs(s)
+            for o in items:
+                seq = o["seq"]
+                size = oracle.size_in_kmer(seq)
+                if kind == abi.PROTEIN and size < 7:
+                    out.append([])
+                    continue
+                pid, km, pos = oix.search(seq, want_positions=True)
+                keep = 0
+                if kind == abi.PROTEIN:
+                    keep = oracle.filter_results(km, size) if len(km) else 0
+                elif len(km) and km[0] >= 10:
+                    _, _, size2 = oracle.set_best_start_codon(km, pos, size, o["starts"], o["plus"], seq, o["start"])
+                    keep = oracle.filter_results(km, size2)
+                out.append(list(zip(pid[:keep].tolist(), km[:keep].tolist())))
+        return out
+
+    exp = [expected(q, k) for q, k in zip(batches, kinds)]
+
+    def check(top, e):
+        pid, km = top.dense()
+        assert top.n_queries == len(e)
+        for i, rep in enumerate(e):
+            k = int(top.top_cnt[i])
+            assert list(zip(pid[i, :k].tolist(), km[i, :k].tolist())) == rep, i
+
+    errors = []
+
+    def worker(i):
+        try:
+            for r in range(4):
+                j = (i + r) % len(batches)
+                check(ix.search_top(packed=batches[j], seq_type=kinds[j]), exp[j])
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(8)]   # more threads than slots: some wait for one
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors
+    # tickets: four batches in flight from one thread, waited for in another order
+    tk = [ix.submit_top(packed=batches[j], seq_type=kinds[j]) for j in (0, 6, 1, 7)]
+    for t, j in sorted(zip(tk, (0, 6, 1, 7)), key=lambda x: -x[1]):
+        check(t.wait(), exp[j])

@@ -8,7 +8,7 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-import torch
+import torch  # noqa: F401  (one HIP runtime for the library)
 
 from kaamer_amd import abi, api, stream, workload
 
@@ -25,18 +25,16 @@ buf, offs = buf[:int(offs[n])], offs[:n + 1]
 reported = [0]
 
 
-def on_chunk(first, n_seqs, c, cnt, rows, pid, km):
-    reported[0] += len(rows)
+def on_chunk(first, n_seqs, top):
+    reported[0] += top.n_reported
 
 
-for n_buf in (1, 2):
+for n_buf in (1, 2, 3):
     s = stream.StreamingSearcher(ix, chunk, chunk * 160, n_buffers=n_buf)
-    s.run(buf[:int(offs[chunk])], offs[:chunk + 1])          # warm-up
-    torch.cuda.synchronize()
+    s.run(buf[:int(offs[2 * chunk])], offs[:2 * chunk + 1])  # warm-up (two chunks: the slots' buffers get their size)
     reported[0] = 0
     t0 = time.perf_counter()
     tot = s.run(buf, offs, on_chunk)
-    torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print("buffers %d: %d reads (%.0f MB) in %.3f s = %.2f M reads/s, %.2e lookups/s PCIe-inclusive; %d ORFs, %d reported"
           % (n_buf, n, len(buf) / 1e6, dt, n / dt / 1e6, tot["n_lookup"] / dt, tot["n_queries"], reported[0]))
