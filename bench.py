@@ -257,7 +257,7 @@ def main():
     def exchange_entries():
         return args.exchange_entries or ((96 << 20) if nucl else (4 << 20)) // world + (1 << 16)
 
-    def exchange_report(searcher, tstream, bufs, offs, sizes, n_pass=6):
+    def exchange_report(searcher, tstream, bufs, offs, sizes, n_pass=6, final_batch=None):
         """per-phase times of the sharded step (events around every phase, one batch at a time), what travelled, and
         how many ranks the RCCL communicator has"""
         from kaamer_amd import sharded
@@ -268,6 +268,10 @@ def main():
                           topn={}, timed=True)
         searcher.finish(tstream)
         ph = searcher.phase_ms
+        final = None
+        if final_batch is not None:   # leave the results of this batch in the workspaces (the parity check reads them)
+            final = searcher.step(bufs[final_batch].data_ptr(), offs[final_batch].data_ptr(), args.queries, sizes[final_batch], tstream)
+            searcher.finish(tstream)
         L = searcher.layout
         bw, W = int(L.block_words), int(L.world)
         hdr = torch.stack([searcher.send[d * bw:d * bw + 4] for d in range(W)]).cpu().numpy()   # [entries, status, nq, owned]
@@ -279,7 +283,7 @@ def main():
                 "phase_batches": ph["batches"],
                 "wire_bytes_per_rank_per_batch": W * searcher.block_bytes,      # fixed-size blocks: what the all-to-all moves
                 "payload_bytes_per_rank_per_batch": payload,                     # headers + counts + entries actually packed
-                "block_entry_capacity": int(L.e_cap), "entries_packed_per_block": [int(h[0]) for h in hdr]}
+                "block_entry_capacity": int(L.e_cap), "entries_packed_per_block": [int(h[0]) for h in hdr]}, final
 
     if sharded_mode:
         from kaamer_amd import sharded
@@ -365,7 +369,9 @@ def main():
         wss[0].finish(streams[0])
         tm_alone = wss[0].kernel_ms_sum()
 
-    exch = exchange_report(searcher, tstream, d_bufs, d_offs, [len(q[0]) for q in batches]) if sharded_mode else None
+    exch = None
+    if sharded_mode:
+        exch, last = exchange_report(searcher, tstream, d_bufs, d_offs, [len(q[0]) for q in batches], final_batch=last_batch)
 
     def sharded_leg(n_batches=12):
         """configs[3]'s data path on this run's database: every rank builds and holds only its hash-prefix shard, all
@@ -407,7 +413,7 @@ def main():
         tt = torch.tensor([dt, float(sum(lookups[i % 2] for i in range(n_batches)))], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt[:1], op=dist.ReduceOp.MAX)
         dist.all_reduce(tt[1:], op=dist.ReduceOp.SUM)   # every rank looks up only the keys its shard owns
-        rep = exchange_report(ss, ts, cbuf, coff, sizes)
+        rep, _ = exchange_report(ss, ts, cbuf, coff, sizes)
         rep.update({"ms_per_batch": float(tt[0]) / n_batches * 1e3, "lookups_per_s": float(tt[1]) / float(tt[0]),
                     "query_seqs_per_s": args.queries * n_batches / float(tt[0]), "batches": n_batches, "scaling": "strong",
                     "shard_build_s_rank0": build_s, "shard_keys_rank0": sst["n_keys"],
@@ -587,14 +593,80 @@ def main():
                 out["parity_checked_queries"] = len(sub)
                 log("parity: %d queries of the last timed batch bit-exact vs oracle" % len(sub))
             if args.host_api:
+                # PCIe-inclusive rates of the C boundary a Go host calls (never `value`): the raw entry points through
+                # ctypes (the GIL is released during a call), results freed at once
+                import ctypes as C
+                import threading
+                L = abi.lib()
+                to = abi.TopnOpts(0.05, 10, 10, 0, None, None, 0, 0)
+                ins = []
+                for qb in batches:
+                    bb = np.ascontiguousarray(qb[0]); oo = np.ascontiguousarray(qb[1])
+                    ins.append((bb, oo, abi.BatchIn(bb.ctypes.data, oo.ctypes.data, len(oo) - 1, seq_type, 0)))
+
+                def one_call(i):
+                    out = C.POINTER(abi.BatchTop)()
+                    abi.check(L.kaamer_search_batch_top(ix._h, C.byref(ins[i % len(ins)][2]), C.byref(to), C.byref(out)))
+                    L.kaamer_batch_top_free(out)
                 hb = {}
-                for name, fn in (("search_batch_top", lambda: ix.search_top(packed=q, seq_type=seq_type)),
-                                 ("search_batch", lambda: ix.search(packed=q, seq_type=seq_type))):
-                    fn()
+                lk_b = float(np.mean([pb["n_lookup"] for pb in per_batch]))
+                n_seq_calls = 4 if nucl else 40
+                for i in range(4):
+                    one_call(i)
+                t0 = time.perf_counter()
+                for i in range(n_seq_calls):
+                    one_call(i)
+                dt = (time.perf_counter() - t0) / n_seq_calls
+                hb["search_batch_top_one_caller"] = {"ms_per_call": dt * 1e3, "lookups_per_s": lk_b / dt}
+                for n_thr in (2, 4, 8):
+                    per = max(2, n_seq_calls // 2)
+
+                    def worker(k):
+                        for i in range(per):
+                            one_call(k * per + i)
+                    th = [threading.Thread(target=worker, args=(k,)) for k in range(n_thr)]
                     t0 = time.perf_counter()
-                    fn()
-                    dt = time.perf_counter() - t0
-                    hb[name] = {"ms": dt * 1e3, "lookups_per_s": per_batch[last_batch]["n_lookup"] / dt}
+                    for t_ in th:
+                        t_.start()
+                    for t_ in th:
+                        t_.join()
+                    dt = (time.perf_counter() - t0) / (n_thr * per)
+                    hb["search_batch_top_%d_callers" % n_thr] = {"ms_per_call": dt * 1e3, "lookups_per_s": lk_b / dt,
+                                                                 "seqs_per_s": args.queries / dt}
+                # streaming (kaamer_stream_push / _pop): chunks of one batch each, three in flight
+                st_h = C.c_void_p()
+                abi.check(L.kaamer_stream_open(ix._h, seq_type, C.byref(to), C.byref(st_h)))
+                n_chunks = 8 if nucl else 64
+                fifo = 0
+
+                def pop_one():
+                    o_ = C.POINTER(abi.BatchTop)()
+                    abi.check(L.kaamer_stream_pop(st_h, C.byref(o_)))
+                    L.kaamer_batch_top_free(o_)
+                t0 = time.perf_counter()
+                for i in range(n_chunks):
+                    bb, oo, _ = ins[i % len(ins)]
+                    while True:
+                        if fifo < 3:
+                            rc = L.kaamer_stream_push(st_h, bb.ctypes.data, oo.ctypes.data, len(oo) - 1)
+                            if rc == 0:
+                                fifo += 1
+                                break
+                            if rc != abi.E_BUSY:
+                                abi.check(rc)
+                        pop_one()
+                        fifo -= 1
+                while fifo:
+                    pop_one()
+                    fifo -= 1
+                dt = (time.perf_counter() - t0) / n_chunks
+                L.kaamer_stream_close(st_h)
+                hb["stream_push_pop_3_in_flight"] = {"ms_per_chunk": dt * 1e3, "lookups_per_s": lk_b / dt, "seqs_per_s": args.queries / dt}
+                ix.search(packed=q, seq_type=seq_type)
+                t0 = time.perf_counter()
+                ix.search(packed=q, seq_type=seq_type)
+                ix.search(packed=q, seq_type=seq_type)
+                hb["search_batch_full_hit_lists"] = {"ms_per_call": (time.perf_counter() - t0) / 2 * 1e3}
                 out["host_buffer_calls_pcie_inclusive"] = hb
             if want_cpu:
                 out["cpu_baseline"] = cpu_baseline(oix, q, seconds=args.cpu_seconds, kind="reads" if nucl else "protein")

@@ -116,6 +116,20 @@ uint32_t kaamer_image_get(const kaamer_image *img, uint32_t key, uint32_t *ids, 
 typedef struct kaamer_proteins kaamer_proteins;
 int kaamer_makedb_fasta(const char *text, uint64_t len, kaamer_proteins **out);
 int kaamer_makedb_tsv(const char *text, uint64_t len, kaamer_proteins **out);
+/*   EMBL:  UniProt flat file (pkg/makedb/inputEMBL.go:46-314).  Records end at a line "//"; record k (1-based
+ *          ordinal of its "//", empty records use up a number) gets id k.  EntryId = first field of the ID line,
+ *          features ProteinName (DE RecName / SubName, " {...};" evidence removed), GeneName, EC, GO, KEGG_ID,
+ *          BioCyc_ID, HAMAP, Organism, TaxId (the reference's [12:] drops the id's first digit: kept),
+ *          FullTaxonomy.  "Flags: Fragment;" entries are dropped.  The length is the one DECLARED on the SQ line:
+ *          entries declaring < 7 are dropped and the k-mers are those of Sequence[:Length].  Not upper-cased, no
+ *          ", partial" filter.
+ *   GBK:   GenPept flat file (inputGBK.go:45-301).  Same record / id rule.  DEFINITION -> ProteinName (a trailing
+ *          " [organism]." removed), VERSION -> EntryId, ORGANISM -> Organism + FullTaxonomy, ORIGIN -> the sequence,
+ *          upper-cased; names containing ", partial" and sequences shorter than 7 are dropped.
+ *   Where the Go code would panic on a malformed entry (a tag line shorter than the column it slices at, an SQ
+ *   length beyond the sequence) the entry is dropped; the split-build options -offset / -length are not reproduced. */
+int kaamer_makedb_embl(const char *text, uint64_t len, kaamer_proteins **out);
+int kaamer_makedb_gbk(const char *text, uint64_t len, kaamer_proteins **out);
 uint32_t kaamer_proteins_count(const kaamer_proteins *p);           /* accepted proteins       */
 const uint32_t *kaamer_proteins_ids(const kaamer_proteins *p);      /* their protein ids       */
 const uint8_t *kaamer_proteins_seqs(const kaamer_proteins *p);      /* packed sequences        */
@@ -426,6 +440,28 @@ int kaamer_exchange_merge(kaamer_workspace *merge_ws, const kaamer_exchange_layo
  * The library does not link RCCL: the symbols are taken from the process (or librccl.so.1). */
 int kaamer_rccl_alltoall(void *nccl_comm, const void *d_send, void *d_recv, uint64_t bytes_per_peer,
                          uint32_t world, void *stream);
+
+/* ------------------------------------------------------------------------- */
+/* One process, one handle, several devices: the reference server   */
+/* is ONE process that opens its stores once and fans out goroutines            */
+/* (api/server.go:47-65, search_fastq.go:60-66).  image i / paths[i] is shard i  */
+/* of n_shards (kaamer_image_build_* (i, n_shards)) and is made resident on      */
+/* devices[i] (the same device may appear more than once).  A call drives all    */
+/* shards from the calling thread: every shard searches the whole batch for the  */
+/* keys it owns, every owner (query q: shard q mod n_shards) pulls its blocks     */
+/* with peer copies over xGMI, merges, runs the post-steps; the reported queries  */
+/* come back in batch order, exactly what kaamer_search_batch_top returns on an   */
+/* unsharded index.  No communicator, no second process.  One batch at a time     */
+/* per handle (calls are serialised).                                            */
+/* ------------------------------------------------------------------------- */
+typedef struct kaamer_sharded_index kaamer_sharded_index;
+int kaamer_index_open_sharded(const char *const *paths, const int *devices, uint32_t n_shards, kaamer_sharded_index **out);
+int kaamer_index_open_sharded_images(const kaamer_image *const *images, const int *devices, uint32_t n_shards,
+                                     kaamer_sharded_index **out);
+uint32_t kaamer_sharded_index_shards(const kaamer_sharded_index *sx);
+void kaamer_sharded_index_close(kaamer_sharded_index *sx);
+int kaamer_sharded_search_batch_top(kaamer_sharded_index *sx, const kaamer_batch_in *in, const kaamer_topn_opts *top,
+                                    kaamer_batch_top **out);
 
 /* Waits for `stream`, copies the counters to the host and reports a deferred
  * KAAMER_E_CAPACITY if a device-side bound was exceeded during the batch. */

@@ -124,6 +124,8 @@ SYMBOLS = {
     "kaamer_image_get": (C.c_uint32, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]),
     "kaamer_makedb_fasta": (C.c_int, [C.c_char_p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "kaamer_makedb_tsv": (C.c_int, [C.c_char_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "kaamer_makedb_embl": (C.c_int, [C.c_char_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "kaamer_makedb_gbk": (C.c_int, [C.c_char_p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "kaamer_proteins_count": (C.c_uint32, [C.c_void_p]),
     "kaamer_proteins_ids": (C.POINTER(C.c_uint32), [C.c_void_p]),
     "kaamer_proteins_seqs": (C.POINTER(C.c_uint8), [C.c_void_p]),
@@ -159,6 +161,11 @@ SYMBOLS = {
     "kaamer_topn_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "kaamer_search_batch_top": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "kaamer_batch_top_free": (None, [C.c_void_p]),
+    "kaamer_index_open_sharded": (C.c_int, [C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.c_uint32, C.POINTER(C.c_void_p)]),
+    "kaamer_index_open_sharded_images": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_uint32, C.POINTER(C.c_void_p)]),
+    "kaamer_sharded_index_shards": (C.c_uint32, [C.c_void_p]),
+    "kaamer_sharded_index_close": (None, [C.c_void_p]),
+    "kaamer_sharded_search_batch_top": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "kaamer_submit_batch_top": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "kaamer_wait_batch_top": (C.c_int, [C.c_void_p, C.c_void_p]),
     "kaamer_stream_open": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),

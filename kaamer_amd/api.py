@@ -109,6 +109,14 @@ class Proteins:
         return cls._make(abi.lib().kaamer_makedb_tsv, text)
 
     @classmethod
+    def from_embl(cls, text):
+        return cls._make(abi.lib().kaamer_makedb_embl, text)
+
+    @classmethod
+    def from_gbk(cls, text):
+        return cls._make(abi.lib().kaamer_makedb_gbk, text)
+
+    @classmethod
     def load(cls, path):
         h = C.c_void_p()
         abi.check(abi.lib().kaamer_proteins_load(str(path).encode(), C.byref(h)))
@@ -383,6 +391,56 @@ class Index:
     def close(self):
         if self._h:
             abi.lib().kaamer_index_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ShardedIndex:
+    """kaamer_index_open_sharded*: one handle over W hash-prefix shards, each resident on its own device, driven from
+    one process (no communicator)."""
+
+    def __init__(self, handle):
+        self._h = C.c_void_p(handle)
+
+    @classmethod
+    def from_images(cls, images, devices):
+        n = len(images)
+        arr = (C.c_void_p * n)(*[im._h for im in images])
+        dev = (C.c_int * n)(*devices)
+        h = C.c_void_p()
+        abi.check(abi.lib().kaamer_index_open_sharded_images(arr, dev, n, C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def open(cls, paths, devices):
+        n = len(paths)
+        arr = (C.c_char_p * n)(*[str(p).encode() for p in paths])
+        dev = (C.c_int * n)(*devices)
+        h = C.c_void_p()
+        abi.check(abi.lib().kaamer_index_open_sharded(arr, dev, n, C.byref(h)))
+        return cls(h.value)
+
+    def search_top(self, seqs=None, packed=None, seq_type=abi.PROTEIN, min_k_ratio=0.05, min_k_match=10, max_results=10):
+        buf, offs = packed if packed is not None else pack_sequences(seqs)
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        bi = abi.BatchIn(buf.ctypes.data if len(buf) else None, offs.ctypes.data, len(offs) - 1, seq_type, 0)
+        to = abi.TopnOpts(min_k_ratio, min_k_match, max_results, 0, None, None, 0, 0)
+        out = C.POINTER(abi.BatchTop)()
+        abi.check(abi.lib().kaamer_sharded_search_batch_top(self._h, C.byref(bi), C.byref(to), C.byref(out)))
+        try:
+            return TopResult(out)
+        finally:
+            abi.lib().kaamer_batch_top_free(out)
+
+    def close(self):
+        if self._h:
+            abi.lib().kaamer_sharded_index_close(self._h)
             self._h = None
 
     def __del__(self):

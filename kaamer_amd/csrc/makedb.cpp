@@ -190,6 +190,231 @@ int kaamer_makedb_tsv(const char *text, uint64_t len, kaamer_proteins **out)
     return KAAMER_OK;
 }
 
+}  // extern "C"
+
+// ---- EMBL / GenBank flat files (pkg/makedb/inputEMBL.go, inputGBK.go) ---------------------------------------
+// Both scan loops cut the file at lines that are exactly "//" (inputEMBL.go:95-113, inputGBK.go:94-112): every such
+// line bumps proteinNb, and the text gathered since the previous one -- if there is any -- is queued under that
+// number, so ids are the 1-based ordinal of the record's terminator (an empty record uses up a number).  Text after
+// the last "//" is never queued.  (offset / length, the split-build options, are not reproduced: one file, all of it.)
+namespace {
+
+const std::string *find_feat(const std::vector<std::pair<std::string, std::string>> &f, const char *k)
+{
+    for (auto &kv : f) if (kv.first == k) return &kv.second;
+    return nullptr;
+}
+std::string &feat_ref(std::vector<std::pair<std::string, std::string>> &f, const char *k)
+{
+    for (auto &kv : f) if (kv.first == k) return kv.second;
+    f.emplace_back(k, std::string());
+    return f.back().second;
+}
+std::string trim_right(std::string v, char c) { while (!v.empty() && v.back() == c) v.pop_back(); return v; }
+std::vector<std::string> fields_of(const std::string &v)  // strings.Fields (ASCII white space)
+{
+    std::vector<std::string> out;
+    size_t i = 0;
+    while (i < v.size()) {
+        while (i < v.size() && (v[i] == ' ' || (v[i] >= '\t' && v[i] <= '\r'))) i++;
+        size_t j = i;
+        while (j < v.size() && !(v[j] == ' ' || (v[j] >= '\t' && v[j] <= '\r'))) j++;
+        if (j > i) out.emplace_back(v, i, j - i);
+        i = j;
+    }
+    return out;
+}
+// regexp `<open>.*<close>` replaced by "": from the first `open` that has a `close` after it to the LAST `close`
+std::string drop_greedy(const std::string &v, const char *open, const char *close)
+{
+    const size_t a = v.find(open);
+    if (a == std::string::npos) return v;
+    const size_t b = v.rfind(close);
+    if (b == std::string::npos || b < a + strlen(open)) return v;
+    return v.substr(0, a) + v.substr(b + strlen(close));
+}
+struct Skip {};  // where the Go code would panic (a slice past the end of a short line, [0] of an empty field list)
+std::string from(const std::string &l, size_t a) { if (a > l.size()) throw Skip(); return l.substr(a); }
+
+// processProteinInputEMBL, inputEMBL.go:189-314.  false: the entry contributes nothing
+bool process_embl_entry(const std::string &entry, std::string &entry_id, std::string &seq, std::vector<std::pair<std::string, std::string>> &feat)
+{
+    long long length = 0;
+    size_t p0 = 0;
+    while (p0 <= entry.size()) {
+        size_t nl = entry.find('\n', p0);
+        if (nl == std::string::npos) nl = entry.size();
+        const std::string l = entry.substr(p0, nl - p0);
+        p0 = nl + 1;
+        if (l.size() < 2) continue;                                                   // :201-203
+        const std::string tag = l.substr(0, 2);
+        if (tag == "ID") {                                                            // :205-206
+            const auto f = fields_of(from(l, 5));
+            if (f.empty()) throw Skip();
+            entry_id = f[0];
+        } else if (tag == "GN") {                                                     // :207-211
+            const std::string *g = find_feat(feat, "GeneName");
+            if ((!g || g->empty()) && l.find("Name=") != std::string::npos) {
+                const auto f = fields_of(from(l, 5));
+                if (f.empty()) throw Skip();
+                feat_ref(feat, "GeneName") = trim_right(from(f[0], 5), ';');
+            }
+        } else if (tag == "DE") {                                                     // :212-229
+            const std::string r = from(l, 5);
+            if (r.find("RecName") != std::string::npos) {
+                feat_ref(feat, "ProteinName") = trim_right(drop_greedy(from(l, 19), " {", "};"), ';');
+            } else if (r.find("SubName") != std::string::npos) {
+                const std::string v = trim_right(drop_greedy(from(l, 19), " {", "};"), ';');
+                std::string &pn = feat_ref(feat, "ProteinName");
+                if (!pn.empty()) pn += ";;" + v; else pn = v;
+            } else if (r.find("EC=") != std::string::npos) {
+                feat_ref(feat, "EC") = trim_right(drop_greedy(from(l, 17), " {", "};"), ';');
+            } else if (r.find("Flags: Fragment;") != std::string::npos) {
+                return false;                                                         // protein fragments are skipped
+            }
+        } else if (tag == "OX") {                                                     // :230-232 (the [12:] eats the id's first digit: kept)
+            const auto f = fields_of(from(l, 5));
+            if (f.empty()) throw Skip();
+            feat_ref(feat, "TaxId") = trim_right(from(f[0], 12), ';');
+        } else if (tag == "OS") {                                                     // :233-239
+            const bool had = find_feat(feat, "Organism") != nullptr;
+            std::string &o = feat_ref(feat, "Organism");
+            if (had) o += " ";
+            o += trim_right(from(l, 5), '.');
+        } else if (tag == "OC") {                                                     // :240-244
+            std::string &t = feat_ref(feat, "FullTaxonomy");
+            if (!t.empty()) t += " ";
+            t += from(l, 5);
+        } else if (tag == "DR") {                                                     // :245-281
+            const auto f = fields_of(from(l, 5));
+            if (f.empty()) throw Skip();
+            const char *key = f[0] == "KEGG;" ? "KEGG_ID" : f[0] == "GO;" ? "GO" : f[0] == "BioCyc;" ? "BioCyc_ID" : f[0] == "HAMAP;" ? "HAMAP" : nullptr;
+            if (key) {
+                if (f.size() < 2) throw Skip();
+                const bool had = find_feat(feat, key) != nullptr;
+                std::string &v = feat_ref(feat, key);
+                if (had) v += ";";
+                v += trim_right(f[1], ';');
+            }
+        } else if (tag == "SQ") {                                                     // :282-285
+            const auto f = fields_of(from(l, 5));
+            if (f.size() < 2) throw Skip();
+            length = 0;                                                               // strconv.Atoi, error ignored
+            size_t i = 0;
+            bool neg = false, ok = !f[1].empty();
+            if (ok && (f[1][0] == '+' || f[1][0] == '-')) { neg = f[1][0] == '-'; i = 1; ok = f[1].size() > 1; }
+            long long v = 0;
+            for (; ok && i < f[1].size(); i++) {
+                if (f[1][i] < '0' || f[1][i] > '9' || v > 100000000000ll) { ok = false; break; }
+                v = v * 10 + (f[1][i] - '0');
+            }
+            if (ok) length = neg ? -v : v;
+        } else if (tag == "  ") {                                                     // :287-288
+            for (char c : from(l, 5)) if (c != ' ') seq.push_back(c);
+        }
+    }
+    if (length < KAAMER_KMER_SIZE) return false;                                      // :293-295: the DECLARED length
+    if ((unsigned long long)length > seq.size()) throw Skip();                       // (the k-mer loop :309-312 would slice past the end)
+    seq.resize((size_t)length);                                                       // windows of Sequence[:Length]
+    return true;
+}
+
+// processProteinInputGBK, inputGBK.go:186-301
+bool process_gbk_entry(const std::string &entry, std::string &entry_id, std::string &seq, std::vector<std::pair<std::string, std::string>> &feat)
+{
+    int inside = 0;
+    size_t p0 = 0;
+    while (p0 <= entry.size()) {
+        size_t nl = entry.find('\n', p0);
+        if (nl == std::string::npos) nl = entry.size();
+        const std::string l = entry.substr(p0, nl - p0);
+        p0 = nl + 1;
+        if (l.size() < 2) continue;                                                   // :206-208
+        size_t a = 0, b = l.size();
+        while (a < b && l[a] == ' ') a++;
+        while (b > a && l[b - 1] == ' ') b--;
+        const size_t sp = l.find(' ', a);
+        const std::string tok = l.substr(a, (sp == std::string::npos || sp > b ? b : sp) - a);  // Split(Trim(l, " "), " ")[0]
+        if (tok == "LOCUS" || tok == "ACCESSION" || tok == "KEYWORDS" || tok == "SOURCE" || tok == "COMMENT" || tok == "REFERENCE" ||
+            tok == "DBLINK" || tok == "DBSOURCE") inside = 0;                         // :210-239
+        else if (tok == "DEFINITION") inside = 1;
+        else if (tok == "VERSION") inside = 2;
+        else if (tok == "ORGANISM") inside = 3;
+        else if (tok == "FEATURES") inside = 4;
+        else if (tok == "ORIGIN") inside = 5;
+        else if (tok == "//") inside = 6;
+        if (inside == 1) {                                                            // :242-246
+            std::string &pn = feat_ref(feat, "ProteinName");
+            if (!pn.empty()) pn += " ";
+            pn += from(l, 12);
+        } else if (inside == 2) {                                                     // :247-248
+            const auto f = fields_of(from(l, 12));
+            if (f.empty()) throw Skip();
+            entry_id = f[0];
+        } else if (inside == 3) {                                                     // :249-257
+            const std::string *o = find_feat(feat, "Organism");
+            if (!o || o->empty()) feat_ref(feat, "Organism") = from(l, 12);
+            else {
+                std::string &t = feat_ref(feat, "FullTaxonomy");
+                if (!t.empty()) t += " ";
+                t += from(l, 12);
+            }
+        } else if (inside == 5) {                                                     // :260-263
+            for (char c : from(l, 10)) if (c != ' ') seq.push_back((c >= 'a' && c <= 'z') ? (char)(c - 32) : c);
+        }
+    }
+    const std::string *pn = find_feat(feat, "ProteinName");
+    if (pn && pn->find(", partial") != std::string::npos) return false;               // :268-270
+    if (seq.size() < KAAMER_KMER_SIZE) return false;                                  // :272-277
+    feat_ref(feat, "ProteinName") = drop_greedy(feat_ref(feat, "ProteinName"), " [", "].");  // :279-280
+    return true;
+}
+
+int makedb_flat(const char *text, uint64_t len, bool gbk, kaamer_proteins **out)
+{
+    if (!out || (!text && len)) return kaamer_fail(KAAMER_E_ARG, "makedb_%s: bad argument", gbk ? "gbk" : "embl");
+    *out = nullptr;
+    kaamer_proteins *r = new_proteins();
+    if (!r) return kaamer_fail(KAAMER_E_NOMEM, "makedb");
+    if (gbk) r->feature_names = { "ProteinName", "Organism", "FullTaxonomy" };       // GBK_DEF_FTS, inputGBK.go:41
+    else r->feature_names = { "ProteinName", "GeneName", "EC", "GO", "KEGG_ID", "BioCyc_ID", "HAMAP", "Organism", "TaxId", "FullTaxonomy" };  // inputEMBL.go:43
+    Lines lr{ text, text + len };
+    const char *b, *e;
+    uint32_t protein_nb = 0;
+    std::string entry;
+    while (lr.next(b, e)) {
+        if (e - b == 2 && b[0] == '/' && b[1] == '/') {
+            protein_nb++;
+            if (!entry.empty()) {
+                std::string entry_id, seq;
+                std::vector<std::pair<std::string, std::string>> feat;
+                bool keep = false;
+                try { keep = gbk ? process_gbk_entry(entry, entry_id, seq, feat) : process_embl_entry(entry, entry_id, seq, feat); }
+                catch (const Skip &) { keep = false; }   // the reference process would have died here: the entry is dropped
+                if (keep) {
+                    std::vector<std::string> vals;
+                    for (auto &n : r->feature_names) { const std::string *v = find_feat(feat, n.c_str()); vals.push_back(v ? *v : std::string()); }
+                    add_protein(r, protein_nb, entry_id, seq, vals);
+                }
+                entry.clear();
+            }
+        } else {
+            entry.append(b, e);
+            entry.push_back('\n');
+        }
+    }
+    *out = r;
+    return KAAMER_OK;
+}
+
+}  // namespace
+
+extern "C" {
+int kaamer_makedb_embl(const char *text, uint64_t len, kaamer_proteins **out) { return makedb_flat(text, len, false, out); }
+int kaamer_makedb_gbk(const char *text, uint64_t len, kaamer_proteins **out) { return makedb_flat(text, len, true, out); }
+}
+
+extern "C" {
 uint32_t kaamer_proteins_count(const kaamer_proteins *p) { return p ? (uint32_t)p->ids.size() : 0; }
 const uint32_t *kaamer_proteins_ids(const kaamer_proteins *p) { return p ? p->ids.data() : nullptr; }
 const uint8_t *kaamer_proteins_seqs(const kaamer_proteins *p) { return p ? p->seqs.data() : nullptr; }

@@ -90,3 +90,181 @@ def run_tsv(text):
         out.append((protein_nb, entry_id, seq, feat))      # :140
         protein_nb += 1                                    # :141
     return out
+
+
+# ---- EMBL / GBK (round 3) ---------------------------------------------------------------------------------
+# run_embl   pkg/makedb/inputEMBL.go:46-118 (runEMBL's scan loop) + :189-314 (processProteinInputEMBL)
+# run_gbk    pkg/makedb/inputGBK.go:45-117  (runGBK's scan loop)  + :186-301 (processProteinInputGBK)
+# Where the Go would panic (a slice past the end of a short line, Fields(...)[0] of a blank field list, a declared
+# length beyond the sequence) the restatement raises RefPanic for that entry; the product skips what the panic
+# would have taken down (documented divergence) and the tests keep such inputs apart.
+import re as _re
+
+EMBL_DEF_FTS = [b"ProteinName", b"GeneName", b"EC", b"GO", b"KEGG_ID", b"BioCyc_ID", b"HAMAP", b"Organism", b"TaxId", b"FullTaxonomy"]
+GBK_DEF_FTS = [b"ProteinName", b"Organism", b"FullTaxonomy"]
+
+
+class RefPanic(Exception):
+    pass
+
+
+def _sl(l, a):
+    """Go l[a:]: panics when a > len(l)"""
+    if a > len(l):
+        raise RefPanic("slice bounds out of range")
+    return l[a:]
+
+
+def _fields(s):
+    return s.split()       # strings.Fields: runs of white space (ASCII inputs)
+
+
+def _first(fs):
+    if not fs:
+        raise RefPanic("index out of range")
+    return fs[0]
+
+
+def _entries(text):
+    """the scan loops (inputEMBL.go:95-113, inputGBK.go:94-112) with offset 0 and the default length:
+    -> [(protein id, entry text)]"""
+    out = []
+    protein_nb = 0
+    entry = b""
+    for line in _scan_lines(text):
+        if line == b"//":
+            protein_nb += 1
+            if entry != b"":
+                out.append((protein_nb, entry))
+                entry = b""
+        else:
+            entry += line + b"\n"
+    return out
+
+
+_EMBL_REG = _re.compile(rb" \{.*\};")
+
+
+def process_embl(entry):
+    """-> None (skipped) | (entry_id, sequence, declared length, features)"""
+    entry_id, seq, length = b"", b"", 0
+    feat = {}
+    for l in entry.split(b"\n"):
+        if len(l) < 2:
+            continue
+        tag = l[0:2]
+        if tag == b"ID":
+            entry_id = _first(_fields(_sl(l, 5)))
+        elif tag == b"GN":
+            if feat.get(b"GeneName", b"") == b"" and b"Name=" in l:
+                feat[b"GeneName"] = _sl(_first(_fields(_sl(l, 5))), 5).rstrip(b";")
+        elif tag == b"DE":
+            if b"RecName" in _sl(l, 5):
+                feat[b"ProteinName"] = _EMBL_REG.sub(b"", _sl(l, 19)).rstrip(b";")
+            elif b"SubName" in _sl(l, 5):
+                v = _EMBL_REG.sub(b"", _sl(l, 19)).rstrip(b";")
+                if feat.get(b"ProteinName", b"") != b"":
+                    feat[b"ProteinName"] += b";;" + v
+                else:
+                    feat[b"ProteinName"] = v
+            elif b"EC=" in _sl(l, 5):
+                feat[b"EC"] = _EMBL_REG.sub(b"", _sl(l, 17)).rstrip(b";")
+            elif b"Flags: Fragment;" in _sl(l, 5):
+                return None
+        elif tag == b"OX":
+            feat[b"TaxId"] = _sl(_first(_fields(_sl(l, 5))), 12).rstrip(b";")
+        elif tag == b"OS":
+            if b"Organism" in feat:
+                feat[b"Organism"] += b" " + _sl(l, 5).rstrip(b".")
+            else:
+                feat[b"Organism"] = _sl(l, 5).rstrip(b".")
+        elif tag == b"OC":
+            if feat.get(b"FullTaxonomy", b"") != b"":
+                feat[b"FullTaxonomy"] += b" "
+            feat[b"FullTaxonomy"] = feat.get(b"FullTaxonomy", b"") + _sl(l, 5)
+        elif tag == b"DR":
+            fields = _fields(_sl(l, 5))
+            key = {b"KEGG;": b"KEGG_ID", b"GO;": b"GO", b"BioCyc;": b"BioCyc_ID", b"HAMAP;": b"HAMAP"}.get(_first(fields))
+            if key is not None:
+                if len(fields) < 2:
+                    raise RefPanic("index out of range")
+                if key in feat:
+                    feat[key] += b";" + fields[1].rstrip(b";")
+                else:
+                    feat[key] = fields[1].rstrip(b";")
+        elif tag == b"SQ":
+            fields = _fields(_sl(l, 5))
+            if len(fields) < 2:
+                raise RefPanic("index out of range")
+            try:
+                length = int(fields[1]) if _re.fullmatch(rb"[+-]?[0-9]+", fields[1]) else 0   # strconv.Atoi, error ignored
+            except ValueError:
+                length = 0
+            if not -2**31 <= length < 2**31:
+                length = 0 if abs(length) >= 2**63 else ((length + 2**31) % 2**32) - 2**31     # Atoi range error -> clamp; int32() wraps
+        elif tag == b"  ":
+            seq += _sl(l, 5).replace(b" ", b"")
+    if length < KMER_SIZE:
+        return None
+    if length > len(seq):
+        raise RefPanic("sequence shorter than its declared length")
+    return entry_id, seq, length, feat
+
+
+def run_embl(text):
+    """-> [(protein id, entry id, indexed residues = Sequence[:Length], stored sequence, features)]"""
+    out = []
+    for pid, entry in _entries(text):
+        r = process_embl(entry)
+        if r is not None:
+            entry_id, seq, length, feat = r
+            out.append((pid, entry_id, seq[:length], seq, feat))
+    return out
+
+
+_GBK_STATE = {b"LOCUS": 0, b"DEFINITION": 1, b"ACCESSION": 0, b"VERSION": 2, b"KEYWORDS": 0, b"SOURCE": 0, b"ORGANISM": 3,
+              b"COMMENT": 0, b"FEATURES": 4, b"ORIGIN": 5, b"//": 6, b"REFERENCE": 0, b"DBLINK": 0, b"DBSOURCE": 0}
+_GBK_REG = _re.compile(rb" \[.*\]\.")
+
+
+def process_gbk(entry):
+    entry_id, seq = b"", b""
+    feat = {}
+    inside = 0
+    for l in entry.split(b"\n"):
+        if len(l) < 2:
+            continue
+        tok = l.strip(b" ").split(b" ")[0]
+        inside = _GBK_STATE.get(tok, inside)
+        if inside == 1:
+            if feat.get(b"ProteinName", b"") != b"":
+                feat[b"ProteinName"] += b" "
+            feat[b"ProteinName"] = feat.get(b"ProteinName", b"") + _sl(l, 12)
+        elif inside == 2:
+            entry_id = _first(_fields(_sl(l, 12)))
+        elif inside == 3:
+            if feat.get(b"Organism", b"") == b"":
+                feat[b"Organism"] = _sl(l, 12)
+            else:
+                if feat.get(b"FullTaxonomy", b"") != b"":
+                    feat[b"FullTaxonomy"] += b" "
+                feat[b"FullTaxonomy"] = feat.get(b"FullTaxonomy", b"") + _sl(l, 12)
+        elif inside == 5:
+            if _sl(l, 10) != b"":
+                seq += _sl(l, 10).replace(b" ", b"").upper()
+    if b", partial" in feat.get(b"ProteinName", b""):
+        return None
+    if len(seq) < KMER_SIZE:
+        return None
+    feat[b"ProteinName"] = _GBK_REG.sub(b"", feat.get(b"ProteinName", b""))
+    return entry_id, seq, len(seq), feat
+
+
+def run_gbk(text):
+    out = []
+    for pid, entry in _entries(text):
+        r = process_gbk(entry)
+        if r is not None:
+            entry_id, seq, length, feat = r
+            out.append((pid, entry_id, seq, seq, feat))
+    return out

@@ -230,3 +230,184 @@ def test_random_tsv_and_nasty_fasta_against_the_restatement(klib):
         last = {r[0]: r for r in ref}
         for e, i in zip(p.fetch_hits(sorted(last)), sorted(last)):
             assert (e["EntryId"], e["Features"][b"ProteinName"]) == (last[i][1], last[i][3][b"ProteinName"]), text
+
+
+# ---- EMBL / GBK (pkg/makedb/inputEMBL.go, inputGBK.go) -----------------------------------------------------
+EMBL = b"""ID   001R_FRG3G              Reviewed;         20 AA.
+AC   Q6GZX4;
+DE   RecName: Full=Putative transcription factor 001R {ECO:0000305};
+DE   SubName: Full=Second name {ECO:1}; extra {ECO:2};
+GN   Name=tf1; ORFNames=FV3-001R;
+OS   Frog virus 3
+OS   (isolate Goorha).
+OC   Viruses; Varidnaviria;
+OC   Bamfordvirae.
+OX   NCBI_TaxID=654924;
+DR   GO; GO:0046782; P:regulation of viral transcription; IEA:InterPro.
+DR   GO; GO:0000001; F:x.
+DR   KEGG; vg:2947773; -.
+DR   EMBL; AY548484; AAT09660.1; -; Genomic_DNA.
+SQ   SEQUENCE   20 AA;  29735 MW;  B4840739BF7D4121 CRC64;
+     MAFSAEDVLK EYDRRRRMEA
+//
+//
+ID   FRAG_X   Unreviewed;  30 AA.
+DE   SubName: Full=Some fragment;
+DE   Flags: Fragment;
+SQ   SEQUENCE   30 AA;  1 MW;  0 CRC64;
+     MAFSAEDVLK EYDRRRRMEA MAFSAEDVLK
+//
+ID   SHORT_Y   Unreviewed;  6 AA.
+SQ   SEQUENCE   6 AA;  1 MW;  0 CRC64;
+     MAFSAE
+//
+ID   lower_z   Unreviewed;  12 AA.
+DE   RecName: Full=lower case stays, partial;
+DE            EC=1.1.1.1 {ECO:3};
+SQ   SEQUENCE   12 AA;  1 MW;  0 CRC64;
+     mafsaedvlk ey
+     extra residues beyond the declared length are not indexed
+//
+ID   NOT_TERMINATED   Unreviewed;  20 AA.
+SQ   SEQUENCE   20 AA;  1 MW;  0 CRC64;
+     MAFSAEDVLK EYDRRRRMEA
+"""
+
+GBK = b"""LOCUS       WP_000000001             20 aa            linear   BCT 01-JAN-2020
+DEFINITION  MULTISPECIES: hypothetical protein
+            [Escherichia coli].
+ACCESSION   WP_000000001
+VERSION     WP_000000001.1
+KEYWORDS    RefSeq.
+SOURCE      Escherichia coli
+  ORGANISM  Escherichia coli
+            Bacteria; Proteobacteria;
+            Gammaproteobacteria.
+FEATURES             Location/Qualifiers
+     source          1..20
+ORIGIN      
+        1 mafsaedvlk eydrrrrmea
+//
+LOCUS       WP_2                     20 aa
+DEFINITION  some enzyme, partial [Bacillus].
+VERSION     WP_2.1
+ORIGIN      
+        1 mafsaedvlk eydrrrrmea
+//
+LOCUS       WP_3                     5 aa
+DEFINITION  tiny [X].
+VERSION     WP_3.1
+ORIGIN      
+        1 mafsa
+//
+LOCUS       WP_4                     12 aa
+DEFINITION  last one [Y]. trailing
+VERSION     WP_4.2
+ORIGIN      
+        1 acdefghikl mn
+//
+"""
+
+
+def _check_flat(p, ref, names):
+    buf, offs = p.packed
+    got = [(int(i), bytes(buf[int(offs[j]):int(offs[j + 1])])) for j, i in enumerate(p.ids)]
+    assert got == [(r[0], r[2]) for r in ref]
+    assert p.feature_names == names
+    for e, r in zip(p.fetch_hits([r[0] for r in ref]), ref):
+        assert e["EntryId"] == r[1]
+        assert {k: v for k, v in e["Features"].items() if v != b""} == {k: v for k, v in r[4].items() if v != b""}
+
+
+def test_embl_rules_match_the_reference(klib, oracle):
+    R = _makedb_ref()
+    ref = R.run_embl(EMBL)
+    # record 1 -> id 1; the empty record uses up id 2; the fragment (3) and the short one (4) are dropped; 5 is kept as
+    # it is (no upper-casing, ", partial" is no filter here) and indexed up to its declared length; the unterminated
+    # record is never queued
+    assert [(r[0], r[1], r[2]) for r in ref] == [(1, b"001R_FRG3G", b"MAFSAEDVLKEYDRRRRMEA"), (5, b"lower_z", b"mafsaedvlkey")]
+    assert ref[0][4] == {b"ProteinName": b"Putative transcription factor 001R;;Second name", b"GeneName": b"tf1", b"Organism": b"Frog virus 3 (isolate Goorha)",
+                         b"FullTaxonomy": b"Viruses; Varidnaviria; Bamfordvirae.", b"TaxId": b"54924", b"GO": b"GO:0046782;GO:0000001",
+                         b"KEGG_ID": b"vg:2947773"}
+    assert ref[1][4] == {b"ProteinName": b"lower case stays, partial", b"EC": b"1.1.1.1"}
+    p = api.Proteins.from_embl(EMBL)
+    _check_flat(p, ref, R.EMBL_DEF_FTS)
+    st = p.stats()
+    assert (st["NumberOfProteins"], st["NumberOfAA"], st["NumberOfKmers"]) == (2, 32, 20)
+    img = p.image()
+    _image_pairs(img, _pairs_of(ref, oracle))
+    assert img.get(oracle.encode_kmer("mafsaed")).tolist() == [5]      # lower case: every pair is a map miss -> key 0 region
+    assert img.get(oracle.encode_kmer("MAFSAED")).tolist() == [1]
+
+
+def test_gbk_rules_match_the_reference(klib, oracle):
+    R = _makedb_ref()
+    ref = R.run_gbk(GBK)
+    assert [(r[0], r[1], r[2]) for r in ref] == [(1, b"WP_000000001.1", b"MAFSAEDVLKEYDRRRRMEA"), (4, b"WP_4.2", b"ACDEFGHIKLMN")]
+    assert ref[0][4] == {b"ProteinName": b"MULTISPECIES: hypothetical protein", b"Organism": b"Escherichia coli",
+                         b"FullTaxonomy": b"Bacteria; Proteobacteria; Gammaproteobacteria."}
+    assert ref[1][4][b"ProteinName"] == b"last one trailing"
+    p = api.Proteins.from_gbk(GBK)
+    _check_flat(p, ref, R.GBK_DEF_FTS)
+    _image_pairs(p.image(), _pairs_of(ref, oracle))
+
+
+def test_random_embl_and_gbk_against_the_restatement(klib):
+    """records assembled at random from well-formed and odd lines (repeated tags, tags in the wrong place, CR line ends,
+    empty records, no terminator); lines on which the Go would panic are only drawn into entries of their own, where
+    restatement (RefPanic) and product (entry dropped) are compared as such"""
+    R = _makedb_ref()
+    rng = np.random.default_rng(29)
+    embl_lines = [b"ID   P%d_X   Reviewed;  %d AA.", b"DE   RecName: Full=Name %d {ECO:1};", b"DE   SubName: Full=Sub %d;;",
+                  b"DE            EC=2.7.%d.1;", b"DE   Flags: Precursor;", b"GN   Name=g%d;", b"GN   ORFNames=o%d;", b"OS   Org %d.",
+                  b"OC   Tax%d; More.", b"OX   NCBI_TaxID=12345%d;", b"DR   GO; GO:%d; F:x.", b"DR   KEGG; k:%d; -.", b"DR   BioCyc; B:%d; -.",
+                  b"DR   HAMAP; MF_%d; x.", b"DR   Pfam; PF%d; x.", b"XX", b"X", b"", b"CC   free text %d", b"     MAFSAEDVLK EYDRRRRMEA",
+                  b"     mktay iakqr", b"     A", b"SQ   SEQUENCE   %d AA;  1 MW;  0 CRC64;"]
+    embl_panics = [b"ID", b"DE  RecName: short", b"OX   x", b"DR   ", b"SQ   SEQUENCE", b"GN   Name=", b"SQ   SEQUENCE   999 AA;"]
+    gbk_lines = [b"LOCUS       L%d   10 aa", b"DEFINITION  protein %d [Org]. tail", b"DEFINITION  enzyme, partial [Org].", b"            continued [Other].",
+                 b"ACCESSION   A%d", b"VERSION     V%d.1  GI:1", b"KEYWORDS    .", b"SOURCE      src", b"  ORGANISM  Org %d", b"            Bacteria; X%d.",
+                 b"COMMENT     c", b"FEATURES             Location/Qualifiers", b"     source          1..%d", b"ORIGIN      ", b"ORIGIN", b"        1 mafsaedvlk eydrrrrmea",
+                 b"       21 acdefghikl", b"        1 mktay", b"REFERENCE   1", b"DBSOURCE    x", b"X", b""]
+    gbk_panics = [b"DEFINITION", b"VERSION", b"VERSION     ", b"  ORGANISM"]
+    for kind, lines, panics, run, make in ((b"embl", embl_lines, embl_panics, R.run_embl, api.Proteins.from_embl),
+                                           (b"gbk", gbk_lines, gbk_panics, R.run_gbk, api.Proteins.from_gbk)):
+        n_kept = 0
+        for trial in range(60):
+            recs = []
+            expect_drop = set()
+            for r in range(int(rng.integers(0, 8))):
+                body = []
+                for _ in range(int(rng.integers(0, 12))):
+                    t = lines[int(rng.integers(0, len(lines)))]
+                    body.append(t.replace(b"%d", b"%d" % int(rng.integers(5, 40))))
+                if rng.random() < 0.5:   # a well-formed end, so that a good share of the records is kept
+                    if kind == b"embl":
+                        body += [b"SQ   SEQUENCE   %d AA;  1 MW;  0 CRC64;" % int(rng.integers(5, 21)), b"     MAFSAEDVLK EYDRRRRMEA"]
+                    else:
+                        body += [b"VERSION     W%d.1" % r, b"ORIGIN      ", b"        1 mafsaedvlk eydrrrrmea"]
+                if trial % 4 == 3 and rng.random() < 0.3:
+                    body.insert(int(rng.integers(0, len(body) + 1)), panics[int(rng.integers(0, len(panics)))])
+                recs.append(body)
+            eol = b"\r\n" if trial % 3 == 0 else b"\n"
+            text = b"".join(eol.join(b + [b"//"]) + eol for b in recs)
+            if trial % 5 == 4:
+                text += eol.join(lines[:3])          # an unterminated tail
+            # the restatement entry by entry, so that a RefPanic drops one entry as the product does
+            ref = []
+            for pid, entry in R._entries(text):
+                try:
+                    got = (R.process_embl if kind == b"embl" else R.process_gbk)(entry)
+                except R.RefPanic:
+                    got = None
+                if got is not None:
+                    entry_id, seq, length, feat = got
+                    ref.append((pid, entry_id, seq[:length], seq, feat))
+            p = make(text)
+            buf, offs = p.packed
+            have = [(int(i), bytes(buf[int(offs[j]):int(offs[j + 1])])) for j, i in enumerate(p.ids)]
+            assert have == [(r[0], r[2]) for r in ref], text
+            for e, r in zip(p.fetch_hits([r[0] for r in ref]), ref):
+                assert e["EntryId"] == r[1], text
+                assert {k: v for k, v in e["Features"].items() if v != b""} == {k: v for k, v in r[4].items() if v != b""}, text
+            n_kept += len(ref)
+        assert n_kept > 20, kind

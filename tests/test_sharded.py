@@ -535,3 +535,66 @@ def test_rccl_alltoall_on_a_real_communicator(klib, oracle, gpu_device):
     assert n > 500
     ss.close()
     comm.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("reads", [False, True], ids=["protein", "reads"])
+def test_single_process_sharded_handle(klib, oracle, gpu_device, reads):
+    """kaamer_index_open_sharded_images + kaamer_sharded_search_batch_top: ONE process drives W shards (here all placed
+    on device 0: peer copies become device-to-device copies), the reported queries come back in batch order and equal
+    both the unsharded kaamer_search_batch_top and the oracle's per-query block on the whole database; W = 1, 2, 3,
+    and the shards saved to files and opened by path."""
+    import tempfile
+    from kaamer_amd import abi, api, workload
+    db = workload.make_db(600, seed=6)
+    full = oracle.Index.from_proteins(None, packed=db)
+    if reads:
+        q = workload.make_reads(db, 300, seed=12)
+        queries = [o for r in workload.unpack(q) for o in oracle.get_orfs(r)]
+        seq_type = abi.READS
+    else:
+        seqs = workload.unpack(workload.make_protein_queries(db, 150, seed=7)) + [max(workload.unpack(db), key=len), b"AAAAAAA", b""]
+        q = api.pack_sequences(seqs)
+        queries = seqs
+        seq_type = abi.PROTEIN
+    exp = [_oracle_report(oracle, full, x, reads)[1] for x in queries]
+    ix1 = api.Index.from_image(api.Image.from_proteins(packed=db), gpu_device)
+    ref = ix1.search_top(packed=q, seq_type=seq_type)
+    rpid, rkm = ref.dense()
+    for world in (1, 2, 3):
+        imgs = [api.Image.from_proteins(packed=db, shard=r, n_shards=world) for r in range(world)]
+        if world == 2:   # through files: kaamer_index_open_sharded
+            with tempfile.TemporaryDirectory() as td:
+                paths = []
+                for r, im in enumerate(imgs):
+                    paths.append("%s/shard%d.kgi" % (td, r))
+                    im.save(paths[-1])
+                sx = api.ShardedIndex.open(paths, [gpu_device] * world)
+        else:
+            sx = api.ShardedIndex.from_images(imgs, [gpu_device] * world)
+        for rep in range(2):   # the second call reuses every buffer
+            top = sx.search_top(packed=q, seq_type=seq_type)
+            assert top.n_queries == ref.n_queries == len(queries)
+            assert top.rep_query.tolist() == ref.rep_query.tolist(), world
+            assert top.top_off.tolist() == ref.top_off.tolist()
+            assert top.top_pid.tolist() == ref.top_pid.tolist() and top.top_kmatch.tolist() == ref.top_kmatch.tolist()
+            assert top.trim.tolist() == ref.trim.tolist()
+            for f in ("src_seq", "size_in_kmer", "start_position", "end_position", "plus_strand", "aa_len", "aa_off"):
+                assert top.meta[f].tolist() == ref.meta[f].tolist(), (world, f)
+            if reads:
+                assert bytes(top.orf_aa) == bytes(ref.orf_aa)
+                assert top.top_first_pos.tolist() == ref.top_first_pos.tolist()
+            pid, km = top.dense()
+            n = 0
+            for i, e in enumerate(exp):
+                k = int(top.top_cnt[i])
+                assert list(zip(pid[i, :k].tolist(), km[i, :k].tolist())) == e, (world, i)
+                n += k
+            assert n > 100
+            assert top.counters["n_lookup"] == ref.counters["n_lookup"] and top.counters["n_post"] == ref.counters["n_post"]
+            assert top.counters["n_hits"] == ref.counters["n_hits"]
+        sx.close()
+    # a handle whose images are not shard i of n is refused
+    with pytest.raises(abi.KaamerError) as e:
+        api.ShardedIndex.from_images([api.Image.from_proteins(packed=db, shard=1, n_shards=2)] * 2, [gpu_device] * 2)
+    assert e.value.code == abi.E_FORMAT
