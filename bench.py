@@ -473,14 +473,21 @@ def main():
     # HBM traffic from the PMC counters is collected in separate rocprofv3 passes (profiles/); reported here only
     # when this run is the workload those passes measured
     traffic = None
-    try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+    requests = None   # 64-byte fabric requests per batch, from the same PMC passes (FETCH_SIZE + WRITE_SIZE count them)
+    for rnd in ("r03", "r02"):
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", rnd + "_pmc_traffic.json")))
+        except Exception:
+            continue
         for e in pm["runs"]:
             if (e["db_proteins"], e["queries"], e["workload"], e["db"]) == (args.db_proteins, args.queries, args.workload, args.db) \
                     and not (sharded_mode or args.post or args.compact):
                 traffic = e["traffic_bytes_per_batch"]
-    except Exception:
-        pass
+                d_ = pm.get("detail", {}).get(e["workload"], {})
+                if "FETCH_bytes_per_batch_raw" in d_:
+                    requests = (d_["FETCH_bytes_per_batch_raw"] + d_["WRITE_bytes_per_batch_raw"]) / 64.0
+        if traffic is not None:
+            break
     whole_bytes = probe_bytes + count_bytes + rest_bytes
 
     def kern(name, secs, nbytes, extra=None):
@@ -518,6 +525,12 @@ def main():
         "dominant_kernel": kernels[0], "other_kernels": kernels[1:], "timed_launches": n_calls,
         "hip_event_batch_ms": tm["total_ms"] / n_calls,
         "min_bytes_8B_slot": n_pos + n_pos / 8 + 8 * c["n_lookup"] + 4 * n_pos + count_bytes,
+        # the roofline that binds a path of random 64-byte sectors: requests per second against the measured ceiling of
+        # the memory system (tools/random_read_bench.hip: ~52 G requests/s whatever the record size up to 128 B)
+        "random_request_ceiling_G_per_s": 52.0,
+        "requests_per_batch": requests,
+        "requests_per_lookup": (requests / max(c["n_lookup"], 1)) if requests else None,
+        "frac_of_request_ceiling": (requests / step_s / 52e9) if requests else None,
     }
 
     cfg_workload = {"protein": "configs[1]: batches of %d protein queries per GPU vs ",

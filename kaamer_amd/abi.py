@@ -208,7 +208,10 @@ def lib():
     except Exception:
         pass
     L = C.CDLL(LIB_PATH)
+    host_only = bool(os.environ.get("KAAMER_HOST_ONLY"))  # the sanitized CPU build of the host sources (tools/asan)
     for name, (res, args) in SYMBOLS.items():
+        if host_only and not hasattr(L, name):
+            continue
         f = getattr(L, name)  # AttributeError if the library lacks a declared symbol
         f.restype = res
         f.argtypes = args

@@ -9,6 +9,7 @@
 // In the Go integration these stay the reference's own Go code.
 #include "kaamer_internal.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -176,6 +177,38 @@ int32_t kaamer_set_best_start_codon(const uint32_t *kmatch_sorted, const uint32_
     if (new_len > 0 && orf_aa && orf_aa[aa_len - 1] == '*') s--;                   // dna.go:264-266
     *size_in_kmer = s;
     return best_start;
+}
+
+}  // extern "C"
+
+// ---- host post-steps kept bit-compatible with the reference (moved here from search.hip: pure host code, part of
+// the sanitized CPU build, tools/asan) -------------------------------------------------------------------------
+extern "C" {
+
+int64_t kaamer_filter_results(const uint32_t *kmatch_sorted, int64_t n_hits, int32_t size_in_kmer, double min_k_ratio,
+                              int64_t min_k_match, int64_t max_results)
+{
+    // search.go:189-220
+    int64_t last_good = n_hits - 1;
+    for (int64_t i = 0; i < n_hits; i++) {
+        const int64_t km = (int64_t)kmatch_sorted[i];
+        if (((double)km / (double)size_in_kmer) < min_k_ratio || km < min_k_match) {
+            if (last_good == n_hits - 1) last_good = i - 1;
+        }
+    }
+    if (last_good >= max_results) last_good = max_results - 1;
+    return last_good < 0 ? 0 : last_good + 1;
+}
+
+void kaamer_sort_hits(const uint32_t *pid, const uint32_t *kmatch, int64_t n_hits, uint32_t *order)
+{
+    std::vector<uint32_t> idx((size_t)n_hits);
+    for (int64_t i = 0; i < n_hits; i++) idx[(size_t)i] = (uint32_t)i;
+    std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) {
+        if (kmatch[a] != kmatch[b]) return kmatch[a] > kmatch[b];
+        return pid[a] < pid[b];
+    });
+    for (int64_t i = 0; i < n_hits; i++) order[i] = idx[(size_t)i];
 }
 
 }  // extern "C"

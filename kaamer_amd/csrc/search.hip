@@ -486,6 +486,25 @@ struct BigLdsTable {
     __device__ __forceinline__ bool over_limit() const { return false; }
 };
 
+// Pass r of R over a query: only the protein ids of range r are counted (the others belong to another pass).  Every pass
+// sweeps all of the query's postings again, so the passes pay only while they are few: with R from the postings count
+// (R ~ postings / 16 384) and no limit, the monsters of the skewed database (a million postings: 60 passes by ONE
+// workgroup) made the tier 2.5 x slower than the table in HBM (21.8 against 8.6 ms per batch).
+#ifndef G_MAX_PASSES
+#define G_MAX_PASSES 8u
+#endif
+struct RangedLdsTable {
+    BigLdsTable t;
+    uint32_t *nd;
+    uint32_t R, r;
+    __device__ __forceinline__ bool add_n(uint32_t pid, uint32_t pos, uint32_t n, uint32_t &nnew) const
+    {
+        if (R > 1u && (uint32_t)(((uint64_t)(pid * 0x85EBCA6Bu) * R) >> 32) != r) return true;
+        return t.add_n(pid, pos, n, nnew);
+    }
+    __device__ __forceinline__ bool over_limit() const { return false; }
+};
+
 // A slot is 16 bytes {protein id, count, lowest position, -}: one memory line per table add.  As three arrays an add
 // touched three random lines of a table that is megabytes large, and the tier ran at the speed of those line fills and
 // write-backs (14 ms per batch on the skewed database, 53 GB of traffic).
@@ -744,7 +763,7 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
     __shared__ uint32_t s_nd, s_fail, s_cursor;
     constexpr int NWIN = 2;
     __shared__ uint32_t s_pref[WAVES][NWIN * 64];
-    __shared__ unsigned long long s_post, s_off, s_base;
+    __shared__ unsigned long long s_post, s_off, s_base, s_reserved;
     __shared__ LongSink s_long;
     __shared__ uint32_t b_keys[BigLdsTable::CAP], b_val[BigLdsTable::CAP];
 
@@ -825,51 +844,88 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
             }
         }
         __syncthreads();
-        // ---- first attempt: the whole query in the big LDS table
+        // ---- in LDS: the whole query in the big table first; a query with more distinct hits than it holds (a skewed
+        // database: tens of thousands of proteins behind a few motifs) is counted in R passes, pass r taking the protein
+        // ids of range r (a hash of the id): every pass streams the query's postings again -- contiguous lists, mostly
+        // L2 hits -- instead of one random line fill and write-back per posting in a multi-megabyte table in HBM
+        // (6.7 of the skewed batch's 8.5 ms).  The hit list takes space for min(postings, proteins) entries once; the
+        // passes write one after the other.  A pass that overflows doubles R and starts over.
         if (size < 65535) {
             BigLdsTable bt;
             bt.keys = b_keys; bt.val = b_val; bt.nd = &s_nd;
-            for (uint32_t i = tid; i < BigLdsTable::CAP; i += 64 * WAVES) { b_keys[i] = KH_EMPTY_PID; b_val[i] = 0xFFFF0000u; }
-            __syncthreads();
-            pc.clear();
-            for (int32_t r0 = 0; r0 < size && !s_fail; r0 += 64 * WAVES * NWIN) {
-                const bool ok = count_windows<BigLdsTable, NWIN, false>(p, vals, size, r0 + 64 * (int32_t)wv, 64 * WAVES, bt, pc,
-                                                                       s_pref[wv], &s_long);
-                if (!ok) s_fail = 1;
-            }
-            __syncthreads();
-            expand_long(bt);
-            __syncthreads();
-            const uint32_t total = s_nd;
-            const bool fits = s_fail == 0u && total <= BigLdsTable::LIMIT;
-            __syncthreads();
-            if (fits) {
-                if (tid == 0) s_base = total ? tail_alloc(p, total) : 0ull;
-                __syncthreads();
-                const unsigned long long base = s_base;
-                if (base != ~0ull && total > 0) {
-                    for (uint32_t i0 = wv * 64u; i0 < BigLdsTable::CAP; i0 += 64 * WAVES) {
-                        const uint32_t k = b_keys[i0 + lane];
-                        const bool has = k != KH_EMPTY_PID;
-                        const unsigned long long bm = __ballot(has);
-                        uint32_t wbase = 0;
-                        if (lane == 0 && bm) wbase = atomicAdd(&s_cursor, (uint32_t)__popcll(bm));
-                        wbase = __shfl(wbase, 0, 64);
-                        if (has) {
-                            const uint32_t idx = wbase + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull));
-                            const uint32_t v = b_val[i0 + lane];
-                            p.hit_pid[base + idx] = k;
-                            p.hit_km[base + idx] = v & 0xFFFFu;
-                            p.hit_fp[base + idx] = v >> 16;
-                        }
+            uint32_t R = 1;
+            bool q_done = false;
+            if (tid == 0) s_base = ~0ull;
+            while (!q_done && R <= G_MAX_PASSES) {
+                uint32_t written = 0;
+                bool failed = false, no_space = false;
+                for (uint32_t r = 0; r < R; r++) {
+                    __syncthreads();
+                    if (tid == 0) { s_nd = 0; s_fail = 0; s_cursor = 0; s_long.n = 0; }
+                    for (uint32_t i = tid; i < BigLdsTable::CAP; i += 64 * WAVES) { b_keys[i] = KH_EMPTY_PID; b_val[i] = 0xFFFF0000u; }
+                    __syncthreads();
+                    RangedLdsTable rt;
+                    rt.t = bt; rt.nd = &s_nd; rt.R = R; rt.r = r;
+                    pc.clear();
+                    for (int32_t r0 = 0; r0 < size && !s_fail; r0 += 64 * WAVES * NWIN) {
+                        const bool ok = count_windows<RangedLdsTable, NWIN, false>(p, vals, size, r0 + 64 * (int32_t)wv, 64 * WAVES, rt, pc,
+                                                                                  s_pref[wv], &s_long);
+                        if (!ok) s_fail = 1;
                     }
-                    if (wv == 0) tot_hits += total;
+                    __syncthreads();
+                    expand_long(rt);
+                    __syncthreads();
+                    const uint32_t total = s_nd;
+                    if (s_fail != 0u || total > BigLdsTable::LIMIT) { failed = true; break; }
+                    if (s_base == ~0ull && total > 0) {  // (workgroup-uniform: s_base is read after a barrier)
+                        __syncthreads();
+                        if (tid == 0) {
+                            unsigned long long want = total;  // one pass: exactly the hits; more: the bound
+                            if (R > 1) { want = s_post < p.n_proteins ? s_post : p.n_proteins; }
+                            s_base = tail_alloc(p, (uint32_t)(want > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : want));
+                            s_reserved = want;
+                            if (s_base == ~0ull) s_fail = 2;
+                        }
+                        __syncthreads();
+                        if (s_fail == 2u) { no_space = true; break; }
+                    }
+                    const unsigned long long base = s_base;
+                    if (total > 0) {
+                        if ((unsigned long long)written + total > s_reserved) { no_space = true; if (tid == 0) atomicOr(p.status, (uint32_t)ST_POOL_FULL); break; }
+                        for (uint32_t i0 = wv * 64u; i0 < BigLdsTable::CAP; i0 += 64 * WAVES) {
+                            const uint32_t k = b_keys[i0 + lane];
+                            const bool has = k != KH_EMPTY_PID;
+                            const unsigned long long bm = __ballot(has);
+                            uint32_t wbase = 0;
+                            if (lane == 0 && bm) wbase = atomicAdd(&s_cursor, (uint32_t)__popcll(bm));
+                            wbase = __shfl(wbase, 0, 64);
+                            if (has) {
+                                const unsigned long long idx = base + written + wbase + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull));
+                                const uint32_t v = b_val[i0 + lane];
+                                p.hit_pid[idx] = k;
+                                p.hit_km[idx] = v & 0xFFFFu;
+                                p.hit_fp[idx] = v >> 16;
+                            }
+                        }
+                        written += total;
+                    }
                 }
-                if (tid == 0) { p.q_cnt[q] = (base != ~0ull) ? total : 0u; p.hit_off[q] = base == ~0ull ? 0 : base; }
-                __syncthreads();
-                continue;
+                if (no_space) { written = 0; q_done = true; if (tid == 0) s_base = ~0ull; __syncthreads(); }
+                if (!failed) {
+                    q_done = true;
+                    __syncthreads();
+                    const unsigned long long base = s_base;
+                    if (wv == 0 && base != ~0ull) tot_hits += written;
+                    if (tid == 0) { p.q_cnt[q] = (base != ~0ull) ? written : 0u; p.hit_off[q] = (base == ~0ull || written == 0) ? 0 : base; }
+                } else {
+                    // start over with more passes: from the postings count first (ids repeat ~6 times along a shared motif)
+                    const uint32_t r_first = (uint32_t)(s_post / 16384ull) + 2u;
+                    R = R == 1u ? r_first : R * 2u;  // (beyond G_MAX_PASSES: the table in HBM)
+                }
             }
-            if (tid == 0) { s_nd = 0; s_fail = 0; s_cursor = 0; s_long.n = 0; }  // too many distinct hits: the HBM table
+            __syncthreads();
+            if (q_done) continue;
+            if (tid == 0) { s_nd = 0; s_fail = 0; s_cursor = 0; s_long.n = 0; }  // (too many passes: the table in HBM)
             __syncthreads();
         }
         unsigned long long bound = s_post;
@@ -1264,6 +1320,8 @@ struct kaamer_workspace {
     uint64_t x_ecap;
     uint32_t *d_x_dst_off, *d_x_src_off, *d_x_nq_owned, *d_x_pid, *d_x_km, *d_x_fp;
     uint64_t *d_x_ent_off;
+    uint64_t *d_x_tiles;                // tile sums of the exchange's tiled scans
+    size_t x_tiles_cap;
     // reported-only packing of the top-N results (kaamer_search_batch_top), allocated on first use
     uint32_t rep_k;
     uint32_t *d_rep_flag, *d_rep_aalen, *d_rep_query, *d_rep_pid, *d_rep_km, *d_rep_fp;
@@ -1392,7 +1450,7 @@ void kaamer_workspace_free(kaamer_workspace *ws)
                      ws->d_pool_cursor, ws->d_lists, ws->d_list_counts, ws->d_status_out, ws->d_qinfo, ws->d_slots,
                      ws->d_slot_off, ws->d_group_first, ws->d_n_groups, ws->d_pos_words, ws->d_pos_base, ws->d_pos_off, ws->d_pos_bits, ws->d_g_keys,
                      ws->d_counter_replicas, ws->d_counters, ws->d_bsum, ws->d_chain, ws->d_tr_chain, ws->d_sched, ws->d_n_sched, ws->d_group_start, ws->d_lay_total, ws->d_top_cnt, ws->d_top_pid, ws->d_top_km, ws->d_top_fp, ws->d_top_trim, ws->d_top_start, ws->d_top_size, ws->d_rep_flag, ws->d_rep_aalen, ws->d_rep_query, ws->d_rep_pid, ws->d_rep_km, ws->d_rep_fp, ws->d_rep_trim, ws->d_rep_rank, ws->d_rep_eoff, ws->d_rep_aoff, ws->d_rep_off, ws->d_rep_q, ws->d_rep_aa, ws->d_hit_off,
-                     ws->d_hit_pid, ws->d_hit_km, ws->d_hit_fp, ws->d_x_dst_off, ws->d_x_src_off, ws->d_x_nq_owned, ws->d_x_pid, ws->d_x_km, ws->d_x_fp, ws->d_x_ent_off };
+                     ws->d_hit_pid, ws->d_hit_km, ws->d_hit_fp, ws->d_x_dst_off, ws->d_x_src_off, ws->d_x_nq_owned, ws->d_x_pid, ws->d_x_km, ws->d_x_fp, ws->d_x_ent_off, ws->d_x_tiles };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (ws->ev) {
         for (hipEvent_t e : *ws->ev) (void)hipEventDestroy(e);
@@ -1428,7 +1486,9 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
         ws->pos_cap = opts->max_seq_bytes + 64;
     }
     if (ws->q_cap < 1) ws->q_cap = 1;
-    ws->hit_cap = opts->max_hits ? opts->max_hits : (uint64_t)ws->q_cap * 256 + (1u << 20);
+    // default bound of the (query, protein) pairs: 256 per query, but never more than one per residue position (an ORF
+    // batch has millions of queries of ~40 positions: 256 each sized a 1 M-read workspace at 67 GB of hit arrays)
+    ws->hit_cap = opts->max_hits ? opts->max_hits : std::min<uint64_t>((uint64_t)ws->q_cap * 256, ws->pos_cap) + (1u << 20);
     ws->g_slots = opts->g_tier_slots ? opts->g_tier_slots : (32ull << 20);
     {
         // hit arrays: the lists sit at the table layout's offsets (<= 1.5 x positions + 64 per query;
@@ -1979,6 +2039,23 @@ int kaamer_exchange_layout_init(uint32_t world, uint32_t rank, uint32_t max_quer
     return KAAMER_OK;
 }
 
+// scratch of the tiled scans: (world + 1) rows of tile sums
+static int x_tiles(kaamer_workspace *ws, const kaamer_exchange_layout *L, XParams *x)
+{
+    const uint32_t n_tiles = (uint32_t)(((uint64_t)L->q_cap + X_TILE - 1) / X_TILE);
+    const size_t need = (size_t)(L->world + 1) * n_tiles;
+    if (ws->x_tiles_cap < need) {
+        if (ws->d_x_tiles) (void)hipFree(ws->d_x_tiles);
+        ws->d_x_tiles = nullptr; ws->x_tiles_cap = 0;
+        const int rc = dev_alloc(&ws->d_x_tiles, need);
+        if (rc) return rc;
+        ws->x_tiles_cap = need;
+    }
+    x->tile_sum = ws->d_x_tiles;
+    x->n_tiles = n_tiles;
+    return KAAMER_OK;
+}
+
 static void x_fill(XParams &x, const kaamer_exchange_layout *L)
 {
     memset(&x, 0, sizeof x);
@@ -2010,8 +2087,18 @@ int kaamer_exchange_pack(kaamer_workspace *ws, const kaamer_exchange_layout *L, 
     x.send = d_send;
     x.dst_off = ws->d_x_dst_off;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(x_pack_scan_kernel, dim3(L->world), dim3(X_BLOCK), 0, s, x);
-    uint32_t gb = (ws->q_cap + 3) / 4;
+    {
+        const int rc = x_tiles(ws, L, &x);
+        if (rc) return rc;
+    }
+    if (x.n_tiles <= X_SMALL_TILES) {
+        hipLaunchKernelGGL(x_pack_scan_small_kernel, dim3(L->world), dim3(X_BLOCK), 0, s, x);
+    } else {
+        hipLaunchKernelGGL(x_scan_sums_kernel<0>, dim3(x.n_tiles, L->world), dim3(X_BLOCK), 0, s, x);
+        hipLaunchKernelGGL(x_scan_top_kernel<0>, dim3(1), dim3(X_BLOCK), 0, s, x);
+        hipLaunchKernelGGL(x_scan_apply_kernel<0>, dim3(x.n_tiles, L->world), dim3(X_BLOCK), 0, s, x);
+    }
+    uint32_t gb = (ws->q_cap + 15) / 16;  // 16 queries per 256-thread block (X_GROUP lanes each)
     if (gb > (uint32_t)ws->n_cu * 8) gb = (uint32_t)ws->n_cu * 8;
     if (gb < 1) gb = 1;
     hipLaunchKernelGGL(x_pack_copy_kernel, dim3(gb), dim3(256), 0, s, x);
@@ -2060,8 +2147,18 @@ int kaamer_exchange_merge(kaamer_workspace *ws, const kaamer_exchange_layout *L,
     x.with_fp = ws->firstpos ? 1u : 0u;
     x.m_cap = m_cap;
     x.status = ws->d_list_counts + SLOT_STATUS;
-    hipLaunchKernelGGL(x_unpack_scan_kernel, dim3(L->world + 1), dim3(X_BLOCK), 0, s, x);
-    uint32_t gb = (L->q_cap + 3) / 4;
+    {
+        const int rc = x_tiles(ws, L, &x);
+        if (rc) return rc;
+    }
+    if (x.n_tiles <= X_SMALL_TILES) {
+        hipLaunchKernelGGL(x_unpack_scan_small_kernel, dim3(L->world + 1), dim3(X_BLOCK), 0, s, x);
+    } else {
+        hipLaunchKernelGGL(x_scan_sums_kernel<1>, dim3(x.n_tiles, L->world + 1), dim3(X_BLOCK), 0, s, x);
+        hipLaunchKernelGGL(x_scan_top_kernel<1>, dim3(1), dim3(X_BLOCK), 0, s, x);
+        hipLaunchKernelGGL(x_scan_apply_kernel<1>, dim3(x.n_tiles, L->world + 1), dim3(X_BLOCK), 0, s, x);
+    }
+    uint32_t gb = (L->q_cap + 15) / 16;
     if (gb > (uint32_t)ws->n_cu * 8) gb = (uint32_t)ws->n_cu * 8;
     if (gb < 1) gb = 1;
     hipLaunchKernelGGL(x_unpack_copy_kernel, dim3(gb), dim3(256), 0, s, x);
@@ -2155,7 +2252,9 @@ int kaamer_topn_device(kaamer_workspace *ws, const kaamer_topn_opts *opts, void 
     p.best_start = best_start ? 1 : 0;
     p.top_cnt = ws->d_top_cnt; p.top_pid = ws->d_top_pid; p.top_km = ws->d_top_km; p.top_fp = ws->d_top_fp;
     p.trim = ws->d_top_trim; p.start_pos = ws->d_top_start; p.size_out = ws->d_top_size;
-    hipLaunchKernelGGL(topn_kernel, dim3(ws->n_cu * 8), dim3(256), 0, (hipStream_t)stream, p);
+    // lanes per query: a protein query has ~190 hits (a wave), an ORF ~15 (16 lanes: four ORFs per wave)
+    if (src->nucleotide) hipLaunchKernelGGL(topn_kernel<16>, dim3(ws->n_cu * 8), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(topn_kernel<64>, dim3(ws->n_cu * 8), dim3(256), 0, (hipStream_t)stream, p);
     HIPCHK(hipGetLastError());
     out->max_results = opts->max_results;
     out->d_top_cnt = ws->d_top_cnt;
@@ -2452,32 +2551,6 @@ void kaamer_batch_free(kaamer_batch_out *out)
 {
     if (!out) return;
     delete reinterpret_cast<batch_out_owner *>(out);  // pub is the first member
-}
-
-int64_t kaamer_filter_results(const uint32_t *kmatch_sorted, int64_t n_hits, int32_t size_in_kmer, double min_k_ratio,
-                              int64_t min_k_match, int64_t max_results)
-{
-    // search.go:189-220
-    int64_t last_good = n_hits - 1;
-    for (int64_t i = 0; i < n_hits; i++) {
-        const int64_t km = (int64_t)kmatch_sorted[i];
-        if (((double)km / (double)size_in_kmer) < min_k_ratio || km < min_k_match) {
-            if (last_good == n_hits - 1) last_good = i - 1;
-        }
-    }
-    if (last_good >= max_results) last_good = max_results - 1;
-    return last_good < 0 ? 0 : last_good + 1;
-}
-
-void kaamer_sort_hits(const uint32_t *pid, const uint32_t *kmatch, int64_t n_hits, uint32_t *order)
-{
-    std::vector<uint32_t> idx((size_t)n_hits);
-    for (int64_t i = 0; i < n_hits; i++) idx[(size_t)i] = (uint32_t)i;
-    std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) {
-        if (kmatch[a] != kmatch[b]) return kmatch[a] > kmatch[b];
-        return pid[a] < pid[b];
-    });
-    for (int64_t i = 0; i < n_hits; i++) order[i] = idx[(size_t)i];
 }
 
 }  // extern "C"

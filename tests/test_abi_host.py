@@ -16,6 +16,10 @@ def _declared_symbols():
     return sorted(set(re.findall(r"\b(kaamer_[a-z_0-9]+)\s*\(", src)))
 
 
+HOST_ONLY = bool(os.environ.get("KAAMER_HOST_ONLY"))   # the sanitized CPU build holds the host sources only
+
+
+@pytest.mark.skipif(HOST_ONLY, reason="host-only sanitized library")
 def test_library_exports_every_declared_symbol(klib):
     from kaamer_amd import abi
     names = _declared_symbols()
@@ -144,6 +148,7 @@ def test_filter_and_sort_match_oracle(klib, oracle):
                 oracle.filter_results(kms.astype(np.int64), size, *opts)
 
 
+@pytest.mark.skipif(HOST_ONLY, reason="host-only sanitized library")
 def test_no_gpu_fails_loudly(klib):
     """Without a device the index cannot open: an error, never a CPU fallback."""
     import torch

@@ -173,3 +173,35 @@ def test_device_offsets_that_disagree_with_the_batch_size(klib, oracle, gpu_devi
         assert c["n_lookup"] == sum(oracle.size_in_kmer(s) for s in seqs if oracle.size_in_kmer(s) >= 7)
     else:
         assert c["n_queries"] == sum(len(oracle.get_orfs(s)) for s in seqs)
+
+
+def test_zipf_database_parity(klib, oracle, gpu_device):
+    """a skewed database (motifs drawn from a power law: postings lists of thousands of proteins): most queries leave
+    the LDS counting tables, half of them have more distinct hits than the G tier's LDS table holds (up to 30 000) and
+    are counted in several passes over ranges of protein ids; every {protein id -> Kmatch} and first position vs the
+    oracle, through the full-list call and (reported hits) the top-N call"""
+    from kaamer_amd import abi, api, workload
+    db = workload.make_db_zipf(40000, seed=11, n_motifs=1500, zipf_a=1.0, per_residues=60)
+    ix = api.Index.from_image(api.Image.from_proteins(packed=db), gpu_device)
+    oix = oracle.Index.from_proteins(None, packed=db)
+    q = workload.make_protein_queries(db, 200, seed=12)
+    res = ix.search(packed=q)
+    top = ix.search_top(packed=q)
+    tp, tk = top.dense()
+    n_big = 0
+    for i, s in enumerate(workload.unpack(q)):
+        size = oracle.size_in_kmer(s)
+        exp, fp = {}, {}
+        keep = 0
+        if size >= 7:
+            pid, km, pos = oix.search(s, want_positions=True)
+            exp = dict(zip(pid.tolist(), km.tolist()))
+            fp = {int(p): int(np.argmax(pos[j])) for j, p in enumerate(pid)}
+            keep = oracle.filter_results(km, size) if len(km) else 0
+            assert tp[i, :keep].tolist() == pid[:keep].tolist() and tk[i, :keep].tolist() == km[:keep].tolist(), i
+        assert int(top.top_cnt[i]) == keep, i
+        assert res.hits(i) == exp, "query %d" % i
+        assert res.first_pos(i) == fp, "query %d" % i
+        n_big += len(exp) > 6144
+    assert n_big >= 50 and res.counters["n_overflow"] >= 100
+    assert res.counters["n_post"] == sum(int(v) for i in range(res.n_queries) for v in res.hits(i).values())

@@ -14,7 +14,7 @@ import re
 import shutil
 import sys
 
-R = sys.argv[1] if len(sys.argv) > 1 else "r02"
+R = sys.argv[1] if len(sys.argv) > 1 else "r03"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", R)
 DST = os.path.join(ROOT, "profiles")
@@ -47,17 +47,25 @@ def short(k):
 
 
 os.makedirs(DST, exist_ok=True)
-for f in ("bench_default_n1", "bench_under_rocprof", "bench_reads_n1", "bench_reads_under_rocprof", "bench_zipf", "bench_mix",
-          "bench_sharded_w1", "bench_sharded_reads_w1", "bench_post_hostapi", "bench_reads_post"):
-    shutil.copy(os.path.join(SRC, f + ".json"), os.path.join(DST, "%s_%s.json" % (R, f)))
+for f in ("bench_default_n1", "bench_under_rocprof", "bench_inflight1_under_rocprof", "bench_reads_n1", "bench_reads_under_rocprof", "bench_zipf",
+          "bench_zipf_mid", "bench_mix", "bench_sharded_w1", "bench_sharded_reads_w1", "bench_post_hostapi", "bench_reads_post_hostapi"):
+    if os.path.exists(os.path.join(SRC, f + ".json")):
+        shutil.copy(os.path.join(SRC, f + ".json"), os.path.join(DST, "%s_%s.json" % (R, f)))
 for f in ("random_read_bench.txt", "bucket_read_bench.txt", "sq_protein.txt", "sq_reads.txt"):
-    shutil.copy(os.path.join(SRC, f), os.path.join(DST, "%s_%s" % (R, f)))
-shutil.copy(one("stats_protein/*/*_kernel_stats.csv"), os.path.join(DST, R + "_kernel_stats_protein_config1.csv"))
-shutil.copy(one("stats_reads/*/*_kernel_stats.csv"), os.path.join(DST, R + "_kernel_stats_reads_config2.csv"))
+    if os.path.exists(os.path.join(SRC, f)):
+        shutil.copy(os.path.join(SRC, f), os.path.join(DST, "%s_%s" % (R, f)))
+for d, name in (("stats_protein", "_kernel_stats_protein_config1.csv"), ("stats_protein_if1", "_kernel_stats_protein_config1_one_in_flight.csv"),
+                ("stats_reads", "_kernel_stats_reads_config2.csv"), ("stats_sharded", "_kernel_stats_sharded_w1_protein.csv"),
+                ("stats_sharded_reads", "_kernel_stats_sharded_w1_reads.csv")):
+    fs = sorted(glob.glob(os.path.join(SRC, d, "*", "*_kernel_stats.csv")) + glob.glob(os.path.join(SRC, d, "*_kernel_stats.csv")), key=os.path.getmtime)
+    if fs:
+        shutil.copy(fs[-1], os.path.join(DST, R + name))
 
 runs = []
 detail = {}
 for tag, fd, wd in (("protein", "pmc_fetch", "pmc_write"), ("reads", "pmc_fetch_reads", "pmc_write_reads")):
+    if not os.path.exists(os.path.join(SRC, fd + ".json")) or not os.path.exists(os.path.join(SRC, wd + ".json")):
+        continue
     b = last_json_line(os.path.join(SRC, fd + ".json"))
     cfg, c = b["config"], b["counters_per_batch_rank0"]
     fetch, write = counter_sums(fd, "FETCH_SIZE"), counter_sums(wd, "WRITE_SIZE")
@@ -78,8 +86,12 @@ for tag, fd, wd in (("protein", "pmc_fetch", "pmc_write"), ("reads", "pmc_fetch_
         "per_kernel_KiB_per_batch": {"FETCH_SIZE": {short(k): round(v[0] / n_prof, 1) for k, v in fetch.items()},
                                      "WRITE_SIZE": {short(k): round(v[0] / n_prof, 1) for k, v in write.items()}},
         "counters_per_batch": c}
-cal = counter_sums("pmc_cal", "FETCH_SIZE")
-txt = open(os.path.join(SRC, "random_read_bench.txt")).read()
+    # requests the memory system saw: FETCH_SIZE / WRITE_SIZE count 64-byte fabric requests (MI355X_MICROARCH.md)
+    detail[tag]["requests_per_batch"] = int((f_b + w_b) / 64)
+    detail[tag]["requests_per_lookup"] = round((f_b + w_b) / 64 / max(c["n_lookup"], 1), 4)
+have_cal = os.path.isdir(os.path.join(SRC, "pmc_cal")) and os.path.exists(os.path.join(SRC, "random_read_bench.txt"))
+cal = counter_sums("pmc_cal", "FETCH_SIZE") if have_cal else {}
+txt = open(os.path.join(SRC, "random_read_bench.txt")).read() if have_cal else ""
 ceiling = {m.group(1) + "B": float(m.group(2)) for m in re.finditer(r"^record\s+(\d+) B:.*?([\d.]+) G records/s", txt, re.M)}
 out = {
     "what": "HBM traffic of one batch of the hot path (all kernels) from rocprofv3 PMC: separate --pmc FETCH_SIZE and --pmc WRITE_SIZE "

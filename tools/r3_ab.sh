@@ -22,6 +22,10 @@ for r in "$@"; do
     group3) KAAMER_COUNT_GROUP=1 run ab_group_if3 $B ;;
     packreads) run ab_pack_reads $B --workload reads --steps 5 ;;
     groupreads) KAAMER_COUNT_GROUP=1 run ab_group_reads $B --workload reads --steps 5 ;;
+    readspost) run ab_reads_post $B --workload reads --steps 5 --post 1 ;;
+    mix) run ab_mix $B --workload mix --steps 3 ;;
+    zipf) run ab_zipf $B --db zipf --steps 3 ;;
+    zipfmid) run ab_zipf_mid $B --db zipf-mid --steps 3 ;;
     prof) (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/prof_ab -o ab -- python3 $OLDPWD/bench.py --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline --check 0 > /dev/null 2> $OLDPWD/gpurun_out/prof_ab.log)
           f=$(ls -t gpurun_out/prof_ab/*/*kernel_stats.csv gpurun_out/prof_ab/*kernel_stats.csv 2>/dev/null | head -1); echo "prof: $f"; [ -n "$f" ] && cut -d, -f1-4 "$f" | head -8; true ;;
     *) echo "unknown run $r" ;;

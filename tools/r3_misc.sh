@@ -19,6 +19,8 @@ for r in "$@"; do
     shp) run misc_sharded_protein $B --steps 5 --warmup 1 --mode sharded ;;
     shr) run misc_sharded_reads $B --steps 2 --warmup 1 --mode sharded --workload reads ;;
     shptorch) run misc_sharded_protein_torch $B --steps 5 --warmup 1 --mode sharded --transport torch ;;
+    profshr) (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/prof_shr -o shr -- python3 $OLDPWD/bench.py --no-cpu-baseline --check 0 --steps 2 --warmup 1 --mode sharded --workload reads > /dev/null 2> $OLDPWD/gpurun_out/prof_shr.log)
+             f=$(ls -t gpurun_out/prof_shr/*kernel_stats.csv gpurun_out/prof_shr/*/*kernel_stats.csv 2>/dev/null | head -1); echo "prof: $f"; [ -n "$f" ] && cut -d, -f1-4 "$f" | head -24; true ;;
     *) echo "unknown $r" ;;
   esac || exit 1
 done
