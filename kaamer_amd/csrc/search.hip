@@ -719,7 +719,10 @@ __device__ __forceinline__ void mark_invalid_range(unsigned long long *invalid, 
 
 #include "count_group.hip.inc"
 #define PK_ARENA_PROT 1600u
+#ifndef PK_ARENA_ORF
 #define PK_ARENA_ORF 640u
+#endif
+#define PK_ARENA_ORF_LONG 1024u  /* batches of longer sequences (mean > 200 nt): ORFs of a few hundred residues are common */
 #include "count_pack.hip.inc"
 
 // ---- G tier: counting table in HBM, sized from the query's exact postings count -------------------
@@ -1271,7 +1274,7 @@ struct kaamer_workspace {
     bool compact;                       // finish with CSR in query order (scan + gather pass)
     uint64_t *d_csr_off;                // compact form: CSR offsets
     uint32_t *d_c_pid, *d_c_km, *d_c_fp;
-    int g_grid, p_grid, n_cu, pack_grid;
+    int g_grid, p_grid, n_cu, pack_grid, pack_grid_long;
     bool use_group;
     uint32_t pack_shift;                // log2 of the pack window (slots) of a search: 8 for protein, 10 for ORF batches
     // device buffers
@@ -1532,6 +1535,9 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
         if (ke != hipSuccess || pk_per_cu < 1) pk_per_cu = 1;
         if (const char *e = getenv("KAAMER_PACK_PER_CU")) { const int v = atoi(e); if (v >= 1 && v < pk_per_cu) pk_per_cu = v; }
         ws->pack_grid = ws->n_cu * pk_per_cu;
+        int pl = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pl, count_pack_kernel<true, PK_ARENA_ORF_LONG>, 64, 0) != hipSuccess || pl < 1) pl = 1;
+        ws->pack_grid_long = ws->n_cu * pl;
     }
     // the pack window: a protein query's table is ~530 slots, so a window of 512 slots holds one or two table starts
     // (tables up to PK_ARENA - 448 slots at full size); an ORF batch has tables of 64-128 slots: 8-16 ORFs to a pack
@@ -1870,7 +1876,20 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
             uint64_t gg = ((uint64_t)GRP_MIN_TABLE * nq_bound + 3 * pos_bound) / GRP_BUDGET + 1;
             if (gg > (uint64_t)ws->grp_grid) gg = ws->grp_grid;
             launch_group(pc, (int)gg, ws->firstpos, s);
-        } else if (ws->nucleotide) hipLaunchKernelGGL((count_pack_kernel<true, PK_ARENA_ORF>), dim3((unsigned)gb), dim3(64), 0, s, pc);
+        } else if (ws->nucleotide) {
+            // reads of ~150 nt: ORFs of <= 50 residues, tables of 64-128 slots -> the small arena (20 waves per CU);
+            // longer sequences (mixed read lengths, contigs): the arena that holds tables of up to 576 slots, or 66 000
+            // ORFs of a 1 M mixed-read batch went to the G tier (measured: 8.19 -> 6.73 ms for the counting stage of
+            // that batch, while the 150-nt batch loses 0.4 ms with the larger arena)
+            const bool long_orfs = seq_bytes > 200ull * (n_seqs ? n_seqs : 1u);
+            uint64_t g2 = gb;
+            if (long_orfs) {
+                if (g2 > (uint64_t)ws->pack_grid_long) g2 = ws->pack_grid_long;
+                hipLaunchKernelGGL((count_pack_kernel<true, PK_ARENA_ORF_LONG>), dim3((unsigned)g2), dim3(64), 0, s, pc);
+            } else {
+                hipLaunchKernelGGL((count_pack_kernel<true, PK_ARENA_ORF>), dim3((unsigned)g2), dim3(64), 0, s, pc);
+            }
+        }
         else if (ws->firstpos) hipLaunchKernelGGL((count_pack_kernel<true, PK_ARENA_PROT>), dim3((unsigned)gb), dim3(64), 0, s, pc);
         else hipLaunchKernelGGL((count_pack_kernel<false, PK_ARENA_PROT>), dim3((unsigned)gb), dim3(64), 0, s, pc);
     }
