@@ -486,21 +486,25 @@ struct BigLdsTable {
     __device__ __forceinline__ bool over_limit() const { return false; }
 };
 
-// Pass r of R over a query: only the protein ids of range r are counted (the others belong to another pass).  Every pass
-// sweeps all of the query's postings again, so the passes pay only while they are few: with R from the postings count
-// (R ~ postings / 16 384) and no limit, the monsters of the skewed database (a million postings: 60 passes by ONE
-// workgroup) made the tier 2.5 x slower than the table in HBM (21.8 against 8.6 ms per batch).
-#ifndef G_MAX_PASSES
-#define G_MAX_PASSES 8u
-#endif
-struct RangedLdsTable {
-    BigLdsTable t;
-    uint32_t *nd;
-    uint32_t R, r;
-    __device__ __forceinline__ bool add_n(uint32_t pid, uint32_t pos, uint32_t n, uint32_t &nnew) const
+// A query with more distinct hits than the LDS table holds is partitioned by protein-id range (count_global_kernel):
+// these two "tables" take the place of a counting table in the postings sweep -- the first counts the items per range,
+// the second writes them to their range's bucket.  An item is (protein id, position | run length << 16).
+#define G_MAX_RANGES 64u
+__device__ __forceinline__ uint32_t g_range_of(uint32_t pid, uint32_t R) { return (uint32_t)(((uint64_t)(pid * 0x85EBCA6Bu) * R) >> 32); }
+struct RangeHist {
+    uint32_t *cnt, *nd;
+    uint32_t R;
+    __device__ __forceinline__ bool add_n(uint32_t pid, uint32_t, uint32_t, uint32_t &) const { atomicAdd(&cnt[g_range_of(pid, R)], 1u); return true; }
+    __device__ __forceinline__ bool over_limit() const { return false; }
+};
+struct RangeScatter {
+    uint32_t *cur, *nd;
+    uint2 *items;
+    uint32_t R;
+    __device__ __forceinline__ bool add_n(uint32_t pid, uint32_t pos, uint32_t n, uint32_t &) const
     {
-        if (R > 1u && (uint32_t)(((uint64_t)(pid * 0x85EBCA6Bu) * R) >> 32) != r) return true;
-        return t.add_n(pid, pos, n, nnew);
+        items[atomicAdd(&cur[g_range_of(pid, R)], 1u)] = make_uint2(pid, pos | (n << 16));
+        return true;
     }
     __device__ __forceinline__ bool over_limit() const { return false; }
 };
@@ -767,6 +771,7 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
     constexpr int NWIN = 2;
     __shared__ uint32_t s_pref[WAVES][NWIN * 64];
     __shared__ unsigned long long s_post, s_off, s_base, s_reserved;
+    __shared__ uint32_t s_roff[G_MAX_RANGES], s_rcur[G_MAX_RANGES], s_rtotal;  // buckets of a partitioned query
     __shared__ LongSink s_long;
     __shared__ uint32_t b_keys[BigLdsTable::CAP], b_val[BigLdsTable::CAP];
 
@@ -847,88 +852,154 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
             }
         }
         __syncthreads();
-        // ---- in LDS: the whole query in the big table first; a query with more distinct hits than it holds (a skewed
-        // database: tens of thousands of proteins behind a few motifs) is counted in R passes, pass r taking the protein
-        // ids of range r (a hash of the id): every pass streams the query's postings again -- contiguous lists, mostly
-        // L2 hits -- instead of one random line fill and write-back per posting in a multi-megabyte table in HBM
-        // (6.7 of the skewed batch's 8.5 ms).  The hit list takes space for min(postings, proteins) entries once; the
-        // passes write one after the other.  A pass that overflows doubles R and starts over.
+        // ---- in LDS: the whole query in the big table first.  A query with more distinct hits than it holds (a skewed
+        // database: tens of thousands of proteins behind a few motifs) has its postings PARTITIONED by protein-id range
+        // (a hash of the id) into R buckets in the G arena -- one counting sweep for the bucket sizes, one sweep that
+        // scatters (id, position, run length) -- and then every bucket is counted in the LDS table on its own and its
+        // hits appended to the query's list (space for min(postings, proteins) entries is taken once).  Three sweeps of
+        // the query and sequential bucket reads instead of one random line fill and write-back per posting in a
+        // multi-megabyte table in HBM (6.5 of the skewed batch's 8.3 ms); counting the ranges by re-sweeping the whole
+        // query per range (tried first) costs R sweeps and lost for the monsters (profiles/r03_count_kernels.md).
         if (size < 65535) {
             BigLdsTable bt;
             bt.keys = b_keys; bt.val = b_val; bt.nd = &s_nd;
-            uint32_t R = 1;
-            bool q_done = false;
+            bool q_done = false, give_up = false;
+            uint32_t written = 0;
             if (tid == 0) s_base = ~0ull;
-            while (!q_done && R <= G_MAX_PASSES) {
-                uint32_t written = 0;
-                bool failed = false, no_space = false;
-                for (uint32_t r = 0; r < R; r++) {
-                    __syncthreads();
-                    if (tid == 0) { s_nd = 0; s_fail = 0; s_cursor = 0; s_long.n = 0; }
-                    for (uint32_t i = tid; i < BigLdsTable::CAP; i += 64 * WAVES) { b_keys[i] = KH_EMPTY_PID; b_val[i] = 0xFFFF0000u; }
-                    __syncthreads();
-                    RangedLdsTable rt;
-                    rt.t = bt; rt.nd = &s_nd; rt.R = R; rt.r = r;
+            // counts bucket `r` (or, r == R: everything, straight from the postings) in the LDS table and appends its hits
+            auto count_bucket = [&](uint32_t R, uint32_t r, const uint2 *items) -> int {  // 0 ok, 1 table overflow, 2 no space
+                __syncthreads();
+                if (tid == 0) { s_nd = 0; s_fail = 0; s_cursor = 0; s_long.n = 0; }
+                for (uint32_t i = tid; i < BigLdsTable::CAP; i += 64 * WAVES) { b_keys[i] = KH_EMPTY_PID; b_val[i] = 0xFFFF0000u; }
+                __syncthreads();
+                if (R == 1u) {
                     pc.clear();
                     for (int32_t r0 = 0; r0 < size && !s_fail; r0 += 64 * WAVES * NWIN) {
-                        const bool ok = count_windows<RangedLdsTable, NWIN, false>(p, vals, size, r0 + 64 * (int32_t)wv, 64 * WAVES, rt, pc,
-                                                                                  s_pref[wv], &s_long);
+                        const bool ok = count_windows<BigLdsTable, NWIN, false>(p, vals, size, r0 + 64 * (int32_t)wv, 64 * WAVES, bt, pc,
+                                                                               s_pref[wv], &s_long);
                         if (!ok) s_fail = 1;
                     }
                     __syncthreads();
-                    expand_long(rt);
-                    __syncthreads();
-                    const uint32_t total = s_nd;
-                    if (s_fail != 0u || total > BigLdsTable::LIMIT) { failed = true; break; }
-                    if (s_base == ~0ull && total > 0) {  // (workgroup-uniform: s_base is read after a barrier)
-                        __syncthreads();
-                        if (tid == 0) {
-                            unsigned long long want = total;  // one pass: exactly the hits; more: the bound
-                            if (R > 1) { want = s_post < p.n_proteins ? s_post : p.n_proteins; }
-                            s_base = tail_alloc(p, (uint32_t)(want > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : want));
-                            s_reserved = want;
-                            if (s_base == ~0ull) s_fail = 2;
-                        }
-                        __syncthreads();
-                        if (s_fail == 2u) { no_space = true; break; }
-                    }
-                    const unsigned long long base = s_base;
-                    if (total > 0) {
-                        if ((unsigned long long)written + total > s_reserved) { no_space = true; if (tid == 0) atomicOr(p.status, (uint32_t)ST_POOL_FULL); break; }
-                        for (uint32_t i0 = wv * 64u; i0 < BigLdsTable::CAP; i0 += 64 * WAVES) {
-                            const uint32_t k = b_keys[i0 + lane];
-                            const bool has = k != KH_EMPTY_PID;
-                            const unsigned long long bm = __ballot(has);
-                            uint32_t wbase = 0;
-                            if (lane == 0 && bm) wbase = atomicAdd(&s_cursor, (uint32_t)__popcll(bm));
-                            wbase = __shfl(wbase, 0, 64);
-                            if (has) {
-                                const unsigned long long idx = base + written + wbase + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull));
-                                const uint32_t v = b_val[i0 + lane];
-                                p.hit_pid[idx] = k;
-                                p.hit_km[idx] = v & 0xFFFFu;
-                                p.hit_fp[idx] = v >> 16;
-                            }
-                        }
-                        written += total;
+                    expand_long(bt);
+                } else {
+                    uint32_t nnew = 0;
+                    const uint32_t b0 = s_roff[r], b1 = r + 1u < R ? s_roff[r + 1u] : s_rtotal;
+                    for (uint32_t i = b0 + tid; i < b1; i += 64 * WAVES) {
+                        if (s_fail) break;
+                        const uint2 it = items[i];
+                        if (!bt.add_n(it.x, it.y & 0xFFFFu, it.y >> 16, nnew)) s_fail = 1;
                     }
                 }
-                if (no_space) { written = 0; q_done = true; if (tid == 0) s_base = ~0ull; __syncthreads(); }
-                if (!failed) {
-                    q_done = true;
+                __syncthreads();
+                const uint32_t total = s_nd;
+                if (s_fail != 0u || total > BigLdsTable::LIMIT) return 1;
+                if (s_base == ~0ull && total > 0) {  // (workgroup-uniform: read after a barrier)
                     __syncthreads();
-                    const unsigned long long base = s_base;
-                    if (wv == 0 && base != ~0ull) tot_hits += written;
-                    if (tid == 0) { p.q_cnt[q] = (base != ~0ull) ? written : 0u; p.hit_off[q] = (base == ~0ull || written == 0) ? 0 : base; }
-                } else {
-                    // start over with more passes: from the postings count first (ids repeat ~6 times along a shared motif)
-                    const uint32_t r_first = (uint32_t)(s_post / 16384ull) + 2u;
-                    R = R == 1u ? r_first : R * 2u;  // (beyond G_MAX_PASSES: the table in HBM)
+                    if (tid == 0) {
+                        unsigned long long want = total;  // one bucket: exactly the hits; more: the bound
+                        if (R > 1u) want = s_post < p.n_proteins ? s_post : p.n_proteins;
+                        s_base = tail_alloc(p, (uint32_t)(want > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : want));
+                        s_reserved = want;
+                        if (s_base == ~0ull) s_fail = 2;
+                    }
+                    __syncthreads();
+                    if (s_fail == 2u) return 2;
+                }
+                const unsigned long long base = s_base;
+                if (total > 0) {
+                    if ((unsigned long long)written + total > s_reserved) { if (tid == 0) atomicOr(p.status, (uint32_t)ST_POOL_FULL); return 2; }
+                    for (uint32_t i0 = wv * 64u; i0 < BigLdsTable::CAP; i0 += 64 * WAVES) {
+                        const uint32_t k = b_keys[i0 + lane];
+                        const bool has = k != KH_EMPTY_PID;
+                        const unsigned long long bm = __ballot(has);
+                        uint32_t wbase = 0;
+                        if (lane == 0 && bm) wbase = atomicAdd(&s_cursor, (uint32_t)__popcll(bm));
+                        wbase = __shfl(wbase, 0, 64);
+                        if (has) {
+                            const unsigned long long idx = base + written + wbase + (uint32_t)__popcll(bm & ((1ull << lane) - 1ull));
+                            const uint32_t v = b_val[i0 + lane];
+                            p.hit_pid[idx] = k;
+                            p.hit_km[idx] = v & 0xFFFFu;
+                            p.hit_fp[idx] = v >> 16;
+                        }
+                    }
+                    written += total;
+                }
+                return 0;
+            };
+            int rc1 = count_bucket(1u, 0u, nullptr);
+            if (rc1 == 0 || rc1 == 2) q_done = true;
+            if (rc1 == 1) {
+                // ---- partition: bucket sizes, offsets, scatter
+                uint32_t R = (uint32_t)(s_post / 16384ull) + 2u;  // ~3 000 distinct ids per bucket when ids repeat ~6 times
+                if (R > G_MAX_RANGES) R = G_MAX_RANGES;
+                __syncthreads();
+                if (tid < G_MAX_RANGES) s_roff[tid] = 0;
+                if (tid == 0) { s_fail = 0; s_long.n = 0; }
+                __syncthreads();
+                RangeHist rh;
+                rh.cnt = s_roff; rh.nd = &s_nd; rh.R = R;
+                pc.clear();
+                for (int32_t r0 = 0; r0 < size; r0 += 64 * WAVES * NWIN)
+                    count_windows<RangeHist, NWIN, false>(p, vals, size, r0 + 64 * (int32_t)wv, 64 * WAVES, rh, pc, s_pref[wv], &s_long);
+                __syncthreads();
+                expand_long(rh);
+                __syncthreads();
+                if (wv == 0) {  // exclusive prefix of the bucket sizes (R <= 64: one lane each); cursors start at the offsets
+                    const uint32_t v = lane < R ? s_roff[lane] : 0u;
+                    uint32_t inc = v;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const uint32_t t = __shfl_up(inc, o, 64);
+                        if ((int)lane >= o) inc += t;
+                    }
+                    s_roff[lane] = inc - v;
+                    s_rcur[lane] = inc - v;
+                    if (lane == 63) s_rtotal = inc;
+                }
+                __syncthreads();
+                const uint32_t n_items = s_rtotal;
+                if (tid == 0) {  // 8 bytes per item: half a 16-byte slot of the arena
+                    const unsigned long long need = ((unsigned long long)n_items + 1ull) / 2ull + 1ull;
+                    const unsigned long long off = atomicAdd(p.g_cursor, need);
+                    if (off + need > p.g_slots) { atomicOr(p.status, (uint32_t)ST_G_ARENA_FULL); s_off = ~0ull; }
+                    else s_off = off;
+                    s_long.n = 0;
+                }
+                __syncthreads();
+                if (s_off == ~0ull) { give_up = true; q_done = true; }
+                else {
+                    uint2 *items = reinterpret_cast<uint2 *>(p.g_keys + 4ull * s_off);
+                    RangeScatter rsc;
+                    rsc.cur = s_rcur; rsc.items = items; rsc.nd = &s_nd; rsc.R = R;
+                    pc.clear();
+                    for (int32_t r0 = 0; r0 < size; r0 += 64 * WAVES * NWIN)
+                        count_windows<RangeScatter, NWIN, false>(p, vals, size, r0 + 64 * (int32_t)wv, 64 * WAVES, rsc, pc, s_pref[wv], &s_long);
+                    __syncthreads();
+                    expand_long(rsc);
+                    // the buckets were written by this workgroup's own stores into a region nobody has loaded from (g_cursor
+                    // never hands a region out twice within a launch): after the barrier (which drains vmcnt) the loads
+                    // below miss the L1 and find them in the L2
+                    __syncthreads();
+                    bool overflow = false;
+                    for (uint32_t r = 0; r < R && !q_done; r++) {
+                        const int rc = count_bucket(R, r, items);
+                        if (rc == 1) { overflow = true; break; }
+                        if (rc == 2) { q_done = true; give_up = true; }
+                    }
+                    if (!overflow) q_done = true;  // else: a bucket with more distinct ids than the table holds -> the table in HBM
+                    else { written = 0; }
                 }
             }
             __syncthreads();
-            if (q_done) continue;
-            if (tid == 0) { s_nd = 0; s_fail = 0; s_cursor = 0; s_long.n = 0; }  // (too many passes: the table in HBM)
+            if (q_done) {
+                const unsigned long long base = give_up ? ~0ull : s_base;
+                if (wv == 0 && base != ~0ull) tot_hits += written;
+                if (tid == 0) { p.q_cnt[q] = (base != ~0ull) ? written : 0u; p.hit_off[q] = (base == ~0ull || written == 0) ? 0 : base; }
+                __syncthreads();
+                continue;
+            }
+            if (tid == 0) { s_nd = 0; s_fail = 0; s_cursor = 0; s_long.n = 0; }  // (a bucket overflowed: the table in HBM)
             __syncthreads();
         }
         unsigned long long bound = s_post;

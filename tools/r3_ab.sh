@@ -28,6 +28,8 @@ for r in "$@"; do
     zipfmid) run ab_zipf_mid $B --db zipf-mid --steps 3 ;;
     prof) (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/prof_ab -o ab -- python3 $OLDPWD/bench.py --steps 3 --warmup 1 --inflight 1 --no-cpu-baseline --check 0 > /dev/null 2> $OLDPWD/gpurun_out/prof_ab.log)
           f=$(ls -t gpurun_out/prof_ab/*/*kernel_stats.csv gpurun_out/prof_ab/*kernel_stats.csv 2>/dev/null | head -1); echo "prof: $f"; [ -n "$f" ] && cut -d, -f1-4 "$f" | head -8; true ;;
+    profzipf) (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/prof_zipf -o z -- python3 $OLDPWD/bench.py --db zipf --steps 2 --warmup 1 --no-cpu-baseline --check 0 > /dev/null 2> $OLDPWD/gpurun_out/prof_zipf.log)
+          f=$(ls -t gpurun_out/prof_zipf/*kernel_stats.csv gpurun_out/prof_zipf/*/*kernel_stats.csv 2>/dev/null | head -1); echo "prof: $f"; [ -n "$f" ] && cut -d, -f1-4 "$f" | head -8; true ;;
     *) echo "unknown run $r" ;;
   esac || exit 1
 done
