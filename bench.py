@@ -153,7 +153,8 @@ def main():
     ap.add_argument("--sharded-leg", type=int, default=1,
                     help="replicas mode with N > 1: after the timed region also run a short pass of the hash-prefix sharded index "
                          "(configs[3]'s data path: search -> pack -> RCCL all-to-all -> merge -> top-N) on the same database and "
-                         "report it under `sharded_leg` (per-phase ms, bytes exchanged, the rank count RCCL saw); 0 = skip")
+                         "report it under `sharded_leg` (per-phase ms, bytes exchanged, the rank count RCCL saw); 0 = skip; "
+                         "2 = run it at N = 1 too (rehearsal of the code path on one GPU)")
     ap.add_argument("--time-every", type=int, default=16,
                     help="bracket the kernels of every k-th timed launch with HIP events (roofline.achieved is their average)")
     ap.add_argument("--post", type=int, default=0,
@@ -401,18 +402,21 @@ def main():
         for b in range(2):
             ss.step(cbuf[b].data_ptr(), coff[b].data_ptr(), args.queries, sizes[b], ts, topn={})
             lookups.append(ss.finish(ts)[0]["n_lookup"])
-        dist.barrier()
+        if world > 1:
+            dist.barrier()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for i in range(n_batches):
             ss.step(cbuf[i % 2].data_ptr(), coff[i % 2].data_ptr(), args.queries, sizes[i % 2], ts, topn={})
         torch.cuda.synchronize()
-        dist.barrier()
+        if world > 1:
+            dist.barrier()
         dt = time.perf_counter() - t1
         ss.finish(ts)
         tt = torch.tensor([dt, float(sum(lookups[i % 2] for i in range(n_batches)))], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt[:1], op=dist.ReduceOp.MAX)
-        dist.all_reduce(tt[1:], op=dist.ReduceOp.SUM)   # every rank looks up only the keys its shard owns
+        if world > 1:
+            dist.all_reduce(tt[:1], op=dist.ReduceOp.MAX)
+            dist.all_reduce(tt[1:], op=dist.ReduceOp.SUM)   # every rank looks up only the keys its shard owns
         rep, _ = exchange_report(ss, ts, cbuf, coff, sizes)
         rep.update({"ms_per_batch": float(tt[0]) / n_batches * 1e3, "lookups_per_s": float(tt[1]) / float(tt[0]),
                     "query_seqs_per_s": args.queries * n_batches / float(tt[0]), "batches": n_batches, "scaling": "strong",
@@ -424,7 +428,7 @@ def main():
         return rep
 
     leg = None
-    if world > 1 and not sharded_mode and args.sharded_leg:
+    if (world > 1 or args.sharded_leg >= 2) and not sharded_mode and args.sharded_leg:
         try:
             leg = sharded_leg()
         except Exception as e:   # the headline line must survive a failure of the secondary leg

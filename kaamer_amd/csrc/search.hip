@@ -2118,8 +2118,8 @@ int kaamer_merge_device(kaamer_workspace *ws, const uint64_t *d_ent_off, const u
 int kaamer_exchange_layout_init(uint32_t world, uint32_t rank, uint32_t max_queries, uint64_t max_entries_per_peer,
                                 kaamer_exchange_layout *out)
 {
-    if (!out || world == 0 || rank >= world || max_entries_per_peer == 0 || max_entries_per_peer > 0xFFFFFFF0ull)
-        return kaamer_fail(KAAMER_E_ARG, "exchange_layout_init: bad argument");
+    if (!out || world == 0 || world > 64 || rank >= world || max_entries_per_peer == 0 || max_entries_per_peer > 0xFFFFFFF0ull)
+        return kaamer_fail(KAAMER_E_ARG, "exchange_layout_init: bad argument (1 <= world <= 64, rank < world, 0 < entries < 2^32)");
     memset(out, 0, sizeof *out);
     out->world = world;
     out->rank = rank;
