@@ -764,7 +764,10 @@ __device__ __forceinline__ void finalize_body(unsigned long long *replicas, kaam
     if (threadIdx.x < 3) cursors[threadIdx.x * CURSOR_STRIDE] = 0;  // G-tier tail cursor, G arena cursors (count, positions)
 }
 
-__global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams p)
+#ifndef G_MIN_BLOCKS
+#define G_MIN_BLOCKS 1
+#endif
+__global__ __launch_bounds__(64 * G_WAVES, G_MIN_BLOCKS) void count_global_kernel(CountParams p)
 {
     constexpr int WAVES = G_WAVES;
     __shared__ uint32_t s_nd, s_fail, s_cursor;
@@ -809,13 +812,42 @@ __global__ __launch_bounds__(64 * G_WAVES) void count_global_kernel(CountParams 
         uint32_t nnew = 0;
         bool ok = true;
         const uint32_t total = nl ? s_long.total : 0u;
-        for (uint32_t t = tid; t < total; t += 64 * WAVES) {
-            if (s_fail) break;  // (the table gave up: no point in the rest)
-            uint32_t e = 0;  // largest e with prefix[e] <= t
+        // Eight items per thread and round, their arena loads all issued before the first id is used, and the list of an
+        // item found from the previous item's (the next item of a thread is 512 further on: the same list, or the one
+        // after it) instead of a ten-step search in LDS per id.  One dependent (search -> load -> add) chain per id made
+        // a monster query's sweep ~1 500 cycles per id and thread: 0.6 ms for half a million postings, three sweeps per
+        // query, and the tier ended when the slowest workgroup had done two of them (4.5 ms per skewed batch).
+#ifndef G_EXPAND_UNROLL
+#define G_EXPAND_UNROLL 8  /* measured on the skewed batch: 4 -> 5.28 ms, 8 -> 4.36, 16 -> 4.42, 32 -> 4.55 */
+#endif
+        constexpr int EU = G_EXPAND_UNROLL;
+        uint32_t e = 0;  // largest e with prefix[e] <= the thread's current item
+        auto find_list = [&](uint32_t t) {
+            if (e + 1u < nl && s_long.cnt[e + 1u] <= t) {      // not in the current list any more
+                e++;
+                if (e + 1u < nl && s_long.cnt[e + 1u] <= t) {  // nor in the next one: search
+                    e = 0;
 #pragma unroll
-            for (uint32_t sft = LONG_SINK_LIFT; sft > 0; sft >>= 1)
-                if (e + sft < nl && s_long.cnt[e + sft] <= t) e += sft;
-            if (!tab.add_n(p.arena[(uint64_t)s_long.off[e] * 4 + 1 + (t - s_long.cnt[e])], s_long.pos[e], 1u, nnew)) { ok = false; s_fail = 1; }
+                    for (uint32_t sft = LONG_SINK_LIFT; sft > 0; sft >>= 1)
+                        if (e + sft < nl && s_long.cnt[e + sft] <= t) e += sft;
+                }
+            }
+        };
+        for (uint32_t t0 = tid; t0 < total; t0 += EU * 64 * WAVES) {
+            if (s_fail) break;  // (the table gave up: no point in the rest)
+            uint32_t ids[EU], pos_[EU];
+#pragma unroll
+            for (int u = 0; u < EU; u++) {
+                const uint32_t t = t0 + (uint32_t)u * 64 * WAVES;
+                const uint32_t tt = t < total ? t : total - 1u;  // (clamped: the load is issued whatever; used only if t < total)
+                find_list(tt);
+                ids[u] = p.arena[(uint64_t)s_long.off[e] * 4 + 1 + (tt - s_long.cnt[e])];
+                pos_[u] = s_long.pos[e];
+            }
+#pragma unroll
+            for (int u = 0; u < EU; u++)
+                if (t0 + (uint32_t)u * 64 * WAVES < total)
+                    if (!tab.add_n(ids[u], pos_[u], 1u, nnew)) { ok = false; s_fail = 1; }
         }
         const uint32_t wn = wave_total(nnew);
         if (lane == 0 && wn) atomicAdd(&s_nd, wn);
