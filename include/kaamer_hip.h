@@ -92,6 +92,14 @@ int kaamer_image_build_pairs(const kaamer_pair *pairs, uint64_t n, uint32_t shar
 int kaamer_image_build_proteins(const uint8_t *seqs, const uint64_t *offsets,
                                 const uint32_t *ids, uint32_t n_proteins, uint32_t shard,
                                 uint32_t n_shards, double load_factor, kaamer_image **out);
+/* The same build on the device (builder_device.hip): emit, radix sort, unique,
+ * set sharing and bucket placement run on `device`; the image that comes back
+ * is byte-identical to kaamer_image_build_proteins' (pkg/indexdb/indexdb.go:68-132,
+ * pkg/kvstore/kcomb_store.go:42-85 at DB-UR shard size).  Inputs are host buffers. */
+int kaamer_image_build_proteins_device(const uint8_t *seqs, const uint64_t *offsets,
+                                       const uint32_t *ids, uint32_t n_proteins, uint32_t shard,
+                                       uint32_t n_shards, double load_factor, int device,
+                                       kaamer_image **out);
 int kaamer_image_save(const kaamer_image *img, const char *path);
 int kaamer_image_load(const char *path, kaamer_image **out);
 int kaamer_image_get_stats(const kaamer_image *img, kaamer_image_stats *out);
@@ -143,6 +151,9 @@ void kaamer_proteins_free(kaamer_proteins *p);
 /* emit loops + indexdb collapse over the accepted proteins under their ids -> one shard's image */
 int kaamer_image_build_makedb(const kaamer_proteins *p, uint32_t shard, uint32_t n_shards, double load_factor,
                               kaamer_image **out);
+/* the same on `device` (kaamer_image_build_proteins_device) */
+int kaamer_image_build_makedb_device(const kaamer_proteins *p, uint32_t shard, uint32_t n_shards,
+                                     double load_factor, int device, kaamer_image **out);
 /* One Protein entry (protein.proto).  Pointers go into the table and stay valid until it is freed;
  * feature i is features[feature_off[i] .. feature_off[i+1]). */
 typedef struct {
@@ -166,6 +177,11 @@ int kaamer_fetch_hits(const kaamer_proteins *p, const uint32_t *ids, uint32_t n,
 typedef struct kaamer_index kaamer_index;
 
 int kaamer_index_open_image(const kaamer_image *img, int device, kaamer_index **out);
+/* makedb -> serving without an image in between: kaamer_image_build_proteins_device's
+ * table stays on `device` and becomes the index. */
+int kaamer_index_build_proteins(const uint8_t *seqs, const uint64_t *offsets, const uint32_t *ids,
+                                uint32_t n_proteins, uint32_t shard, uint32_t n_shards,
+                                double load_factor, int device, kaamer_index **out);
 int kaamer_index_open(const char *path, int device, kaamer_index **out);
 void kaamer_index_close(kaamer_index *ix);
 int kaamer_index_get_stats(const kaamer_index *ix, kaamer_image_stats *out);

@@ -117,6 +117,10 @@ SYMBOLS = {
                                            C.POINTER(C.c_void_p)]),
     "kaamer_image_build_proteins": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
                                               C.c_uint32, C.c_double, C.POINTER(C.c_void_p)]),
+    "kaamer_image_build_proteins_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                                     C.c_uint32, C.c_double, C.c_int, C.POINTER(C.c_void_p)]),
+    "kaamer_index_build_proteins": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32,
+                                              C.c_uint32, C.c_double, C.c_int, C.POINTER(C.c_void_p)]),
     "kaamer_image_save": (C.c_int, [C.c_void_p, C.c_char_p]),
     "kaamer_image_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "kaamer_image_get_stats": (C.c_int, [C.c_void_p, C.POINTER(ImageStats)]),
@@ -137,6 +141,8 @@ SYMBOLS = {
     "kaamer_proteins_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "kaamer_proteins_free": (None, [C.c_void_p]),
     "kaamer_image_build_makedb": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_double, C.POINTER(C.c_void_p)]),
+    "kaamer_image_build_makedb_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_double, C.c_int,
+                                                   C.POINTER(C.c_void_p)]),
     "kaamer_fetch_hits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(ProteinEntry)]),
     "kaamer_index_open_image": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "kaamer_index_open": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),

@@ -39,7 +39,8 @@ class Image:
         return cls(h.value)
 
     @classmethod
-    def from_proteins(cls, seqs=None, ids=None, packed=None, shard=0, n_shards=1, load_factor=0.5):
+    def from_proteins(cls, seqs=None, ids=None, packed=None, shard=0, n_shards=1, load_factor=0.5, device=None):
+        """device=None: the host builder; device=d: the same image built on GPU d (byte-identical)."""
         buf, offs = packed if packed is not None else pack_sequences(seqs)
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
         offs = np.ascontiguousarray(offs, dtype=np.uint64)
@@ -48,9 +49,14 @@ class Image:
             ids = np.ascontiguousarray(ids, dtype=np.uint32)
             idp = ids.ctypes.data
         h = C.c_void_p()
-        abi.check(abi.lib().kaamer_image_build_proteins(buf.ctypes.data, offs.ctypes.data, idp,
-                                                        len(offs) - 1, shard, n_shards, load_factor,
-                                                        C.byref(h)))
+        if device is None:
+            abi.check(abi.lib().kaamer_image_build_proteins(buf.ctypes.data, offs.ctypes.data, idp,
+                                                            len(offs) - 1, shard, n_shards, load_factor,
+                                                            C.byref(h)))
+        else:
+            abi.check(abi.lib().kaamer_image_build_proteins_device(buf.ctypes.data, offs.ctypes.data, idp,
+                                                                   len(offs) - 1, shard, n_shards, load_factor,
+                                                                   int(device), C.byref(h)))
         return cls(h.value)
 
     @classmethod
@@ -151,9 +157,12 @@ class Proteins:
         abi.lib().kaamer_proteins_stats(self._h, out)
         return dict(NumberOfProteins=out[0], NumberOfAA=out[1], NumberOfKmers=out[2], Features=self.feature_names)
 
-    def image(self, shard=0, n_shards=1, load_factor=0.5):
+    def image(self, shard=0, n_shards=1, load_factor=0.5, device=None):
         h = C.c_void_p()
-        abi.check(abi.lib().kaamer_image_build_makedb(self._h, shard, n_shards, load_factor, C.byref(h)))
+        if device is None:
+            abi.check(abi.lib().kaamer_image_build_makedb(self._h, shard, n_shards, load_factor, C.byref(h)))
+        else:
+            abi.check(abi.lib().kaamer_image_build_makedb_device(self._h, shard, n_shards, load_factor, int(device), C.byref(h)))
         return Image(h.value)
 
     def fetch_hits(self, ids):
@@ -334,6 +343,21 @@ class Index:
     def from_image(cls, image, device=0):
         h = C.c_void_p()
         abi.check(abi.lib().kaamer_index_open_image(image._h, device, C.byref(h)))
+        return cls(h.value, device)
+
+    @classmethod
+    def from_proteins(cls, seqs=None, ids=None, packed=None, shard=0, n_shards=1, load_factor=0.5, device=0):
+        """The table built on the device it is searched on (kaamer_index_build_proteins): no image in between."""
+        buf, offs = packed if packed is not None else pack_sequences(seqs)
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        idp = None
+        if ids is not None:
+            ids = np.ascontiguousarray(ids, dtype=np.uint32)
+            idp = ids.ctypes.data
+        h = C.c_void_p()
+        abi.check(abi.lib().kaamer_index_build_proteins(buf.ctypes.data, offs.ctypes.data, idp, len(offs) - 1, shard,
+                                                        n_shards, load_factor, int(device), C.byref(h)))
         return cls(h.value, device)
 
     @classmethod

@@ -438,6 +438,12 @@ int kaamer_image_build_makedb(const kaamer_proteins *p, uint32_t shard, uint32_t
                                        load_factor, out);
 }
 
+// the packed proteins of a table, for the device builder (builder_device.hip)
+void kaamer_proteins_raw(const kaamer_proteins *p, const uint8_t **seqs, const uint64_t **offsets, const uint32_t **ids, uint32_t *n)
+{
+    *seqs = p->seqs.data(); *offsets = p->offsets.data(); *ids = p->ids.data(); *n = (uint32_t)p->ids.size();
+}
+
 // FetchHitsInformation, search.go:454-470: the Protein entry of each hit (protein.proto: EntryId, Sequence,
 // Length, Features), from the table instead of one ProteinStore point read per hit
 int kaamer_fetch_hits(const kaamer_proteins *p, const uint32_t *ids, uint32_t n, kaamer_protein_entry *out)

@@ -1515,6 +1515,28 @@ int kaamer_index_open_image(const kaamer_image *img, int device, kaamer_index **
     return KAAMER_OK;
 }
 
+// makedb -> serving without an image file in between: the table is built on the device it will be searched on
+int kaamer_index_build_proteins(const uint8_t *seqs, const uint64_t *offsets, const uint32_t *ids, uint32_t n_proteins,
+                                uint32_t shard, uint32_t n_shards, double load_factor, int device, kaamer_index **out)
+{
+    if (!out || !offsets || (!seqs && n_proteins) || n_shards == 0 || shard >= n_shards)
+        return kaamer_fail(KAAMER_E_ARG, "index_build_proteins: bad argument");
+    *out = nullptr;
+    kaamer_device_image di;
+    const int rc = kaamer_build_on_device(seqs, offsets, ids, n_proteins, shard, n_shards, load_factor, device, &di);
+    if (rc) return rc;
+    kaamer_index *ix = new (std::nothrow) kaamer_index();
+    if (!ix) { (void)hipFree(di.d_buckets); (void)hipFree(di.d_arena); return kaamer_fail(KAAMER_E_NOMEM, "index alloc"); }
+    ix->device = device;
+    ix->n_top = 4;
+    if (const char *e = getenv("KAAMER_HOST_SLOTS")) { const int v = atoi(e); if (v >= 1 && v <= KAAMER_MAX_HOST_SLOTS) ix->n_top = v; }
+    ix->hdr = di.hdr;
+    ix->d_buckets = di.d_buckets;
+    ix->d_arena = di.d_arena;   // its first 16 bytes are zero (builder_device.hip), as kaamer_index_open_image leaves them
+    *out = ix;
+    return KAAMER_OK;
+}
+
 int kaamer_index_open(const char *path, int device, kaamer_index **out)
 {
     kaamer_image *img = nullptr;

@@ -86,6 +86,34 @@ def make_db(n_proteins, seed=SEED, family=10, chunk_families=20000):
     return buf, offs
 
 
+def _make_db_span(args):
+    n, seed, family = args
+    return make_db(n, seed=seed, family=family)
+
+
+def make_db_parallel(n_proteins, seed=SEED, family=10, workers=None, span=200000):
+    """A database with make_db's statistics, generated `span` proteins at a time by a pool of processes (each span is
+    make_db under its own seed; families do not cross spans).  For the DB-UR-lite sizes: make_db itself is one thread."""
+    import multiprocessing as mp
+    import os
+    span -= span % family
+    jobs = [(min(span, n_proteins - a), seed + 1 + i, family) for i, a in enumerate(range(0, n_proteins, span))]
+    workers = workers or min(len(jobs), max(1, (os.cpu_count() or 2) - 1))
+    lens = []
+    parts = []
+    with mp.get_context("fork").Pool(workers) as pool:
+        for buf, offs in pool.imap(_make_db_span, jobs):
+            parts.append(buf)
+            lens.append(np.diff(offs.astype(np.int64)))
+    offs = _offsets(np.concatenate(lens))
+    out = np.empty(int(offs[-1]), dtype=np.uint8)
+    at = 0
+    for b in parts:
+        out[at:at + len(b)] = b
+        at += len(b)
+    return out, offs
+
+
 def make_protein_queries(db, n_queries, seed=SEED + 1, member_frac=0.8, subst=0.05):
     """Q-P.  -> (buf, offsets); all queries >= 13 aa (so SizeInKmer >= 7)."""
     buf, offs = db
