@@ -199,6 +199,13 @@ def main():
         args.check = 0   # the oracle's index of the whole database does not fit the bounded check of a bench run
     _tame_malloc()
     import numpy as np
+    ur_db = None
+    if args.db == "ur-lite":
+        # generated by a pool of processes, which must be over before this process touches the GPU
+        from kaamer_amd import workload as _w
+        t0 = time.time()
+        ur_db = _w.make_db_parallel(args.db_proteins, workers=max(1, (os.cpu_count() or 2) // max(1, int(os.environ.get("WORLD_SIZE", "1"))) - 1))
+        log("DB (ur-lite) generated in %.1fs" % (time.time() - t0))
     import torch
     import torch.distributed as dist
 
@@ -221,19 +228,18 @@ def main():
         db = workload.make_db_zipf(args.db_proteins)
     elif args.db == "zipf-mid":   # a tenth of the motif reuse: longest postings list ~1e3
         db = workload.make_db_zipf(args.db_proteins, zipf_a=0.45, per_residues=240)
+    elif ur_db is not None:
+        db = ur_db
     else:
         db = workload.make_db(args.db_proteins)
     log("DB (%s): %d proteins, %d residues (%.1fs)" % (args.db, args.db_proteins, int(db[1][-1]), time.time() - t0))
     t0 = time.time()
-    img = api.Image.from_proteins(packed=db, load_factor=args.load_factor,
-                                  shard=rank if sharded_mode else 0, n_shards=world if sharded_mode else 1)
-    st = img.stats()
-    log("image built in %.1fs: %s" % (time.time() - t0, st))
-    t0 = time.time()
-    ix = api.Index.from_image(img, local_rank)
-    img.close()
+    # the table is built on the device it is searched on (builder_device.hip; byte-identical to the host builder's image)
+    ix = api.Index.from_proteins(packed=db, load_factor=args.load_factor, device=local_rank,
+                                 shard=rank if sharded_mode else 0, n_shards=world if sharded_mode else 1)
+    st = ix.stats()
     table_bytes = st["n_buckets"] * BUCKET_BYTES + st["arena_words"] * 4
-    log("index resident in HBM (%.2f GB) in %.1fs" % (table_bytes / 1e9, time.time() - t0))
+    log("index built on the device and resident in HBM (%.2f GB) in %.1fs: %s" % (table_bytes / 1e9, time.time() - t0, st))
 
     # ---- the batches: same generator, a different seed per batch (and per rank: replicas search their own batches)
     n_distinct = max(1, args.distinct_batches)
@@ -380,10 +386,8 @@ def main():
         the post-steps.  A short secondary measurement next to the replicas headline (strong scaling: the batch is fixed)."""
         from kaamer_amd import sharded
         t0 = time.time()
-        simg = api.Image.from_proteins(packed=db, load_factor=args.load_factor, shard=rank, n_shards=world)
-        sst = simg.stats()
-        six = api.Index.from_image(simg, local_rank)
-        simg.close()
+        six = api.Index.from_proteins(packed=db, load_factor=args.load_factor, shard=rank, n_shards=world, device=local_rank)
+        sst = six.stats()
         build_s = time.time() - t0
         cb = []
         for b in range(2):  # the same batches on every rank
