@@ -189,7 +189,10 @@ def main():
     if args.batches_per_step <= 0:
         args.batches_per_step = 3 if nucl else (20 if args.db.startswith("zipf") else 200)
     if args.inflight <= 0:
-        args.inflight = 1 if (nucl or args.mode == "sharded" or args.db.startswith("zipf")) else 3
+        # batches in flight, each on its own stream and workspace.  The skewed databases gain most: their batches end in
+        # a tail of a few monster queries' workgroups, which the next batches' kernels fill (1 / 2 / 3 / 4 / 6 in flight:
+        # 4.28 / 2.32 / 1.67 / 1.42 / 1.78 ms per batch); 1 M-read batches fill the device on their own (6.86 / 6.70 / 6.41)
+        args.inflight = 1 if (nucl or args.mode == "sharded") else (4 if args.db == "zipf" else 3)
     if args.db.startswith("zipf"):
         args.g_tier_slots = args.g_tier_slots or (1 << 30)
         args.max_hits = args.max_hits or (1 << 28)

@@ -7,6 +7,8 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 run() { f=$1; shift; timeout -k 10 500 python3 bench.py --no-cpu-baseline "$@" > $O/bench_$f.json 2> $O/bench_$f.log || { echo "$f FAILED"; tail -3 $O/bench_$f.log; exit 1; }; }
 run zipf --db zipf
+run zipf_inflight1 --db zipf --inflight 1
+run reads_inflight3 --workload reads --inflight 3
 run zipf_mid --db zipf-mid
 run mix --workload mix
 run sharded_w1 --mode sharded
@@ -17,6 +19,6 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/sta
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_sharded_reads -- python3 bench.py --mode sharded --workload reads --no-cpu-baseline --steps 2 --warmup 1 --check 0 > $O/bench_sharded_reads_prof.json 2> $O/stats_sharded_reads.log || { tail -3 $O/stats_sharded_reads.log; exit 1; }
 python3 - <<PY
 import json
-for f in ("zipf","zipf_mid","mix","sharded_w1","sharded_reads_w1","post_hostapi","reads_post_hostapi"):
+for f in ("zipf","zipf_inflight1","reads_inflight3","zipf_mid","mix","sharded_w1","sharded_reads_w1","post_hostapi","reads_post_hostapi"):
     j=json.load(open("$O/bench_%s.json"%f)); print(f, "value %.3e ms/batch %.4f"%(j["value"], j["config"]["ms_per_batch"]))
 PY
