@@ -260,12 +260,30 @@ def main():
     d_bufs = [torch.from_numpy(q[0]).cuda() for q in batches]
     d_offs = [torch.from_numpy(q[1].view(np.int64)).cuda() for q in batches]
     max_bytes = max(len(q[0]) for q in batches)
+    if args.db == "ur-lite" and not args.max_hits:
+        # a dense database: most k-mers meet several proteins by chance, the counting tables grow with that (the library
+        # scales them from the previous batch's hits per k-mer, up to what the hit arrays were provisioned for)
+        args.max_hits = int(2.0 * int(args.queries * (125 if nucl else 365) * (0.065 + 2.18 * float(int(db[1][-1])) / 1e9) * 1.3))
     ws_kw = dict(seq_type=seq_type, max_hits=args.max_hits or ((64 << 20) if nucl else 0), g_tier_slots=args.g_tier_slots,
                  compact=bool(args.compact))
     stream = torch.cuda.current_stream().cuda_stream
 
     def exchange_entries():
-        return args.exchange_entries or ((96 << 20) if nucl else (4 << 20)) // world + (1 << 16)
+        """entries one (source, destination) block holds.  A batch's partial hits grow with the database: besides the
+        homologues, every k-mer of a query meets the proteins that hold it by chance (pairs of the database / 21^7 per
+        lookup), which on DB-UR-lite outnumber the rest"""
+        if args.exchange_entries:
+            return args.exchange_entries
+        return max((96 << 20) if nucl else (4 << 20), partial_entries()) // world + (1 << 16)
+
+    def partial_entries():
+        lookups = args.queries * (125 if nucl else 365)
+        return int(lookups * (0.065 + 2.18 * float(int(db[1][-1])) / 1e9) * 1.3)   # measured: 0.5 hits per k-mer on DB-SP (2e8 residues), 2.24 at 1e9
+
+    def shard_hits():   # hit-list capacity of a rank's search workspace (0: the library's default)
+        if args.db == "ur-lite":
+            return int(2.0 * partial_entries()) // world + (1 << 20)
+        return max(64 << 20, partial_entries() // world + (1 << 20)) if nucl else 0
 
     def exchange_report(searcher, tstream, bufs, offs, sizes, n_pass=6, final_batch=None):
         """per-phase times of the sharded step (events around every phase, one batch at a time), what travelled, and
@@ -299,7 +317,7 @@ def main():
         from kaamer_amd import sharded
         tstream = torch.cuda.current_stream()
         searcher = sharded.ShardedSearcher(ix, rank, world, max_bytes, args.queries, seq_type=seq_type,
-                                           max_entries_per_peer=exchange_entries(), max_hits=(64 << 20) if nucl else 0,
+                                           max_entries_per_peer=exchange_entries(), max_hits=shard_hits(),
                                            transport=args.transport)
 
         def launch(i):
@@ -403,7 +421,7 @@ def main():
         sizes = [len(q[0]) for q in cb]
         ts = torch.cuda.current_stream()
         ss = sharded.ShardedSearcher(six, rank, world, max(sizes), args.queries, seq_type=seq_type,
-                                     max_entries_per_peer=exchange_entries(), max_hits=(64 << 20) if nucl else 0,
+                                     max_entries_per_peer=exchange_entries(), max_hits=shard_hits(),
                                      transport=args.transport)
         lookups = []
         for b in range(2):

@@ -125,7 +125,8 @@ enum { LIST_S = 0, LIST_L, LIST_SO, LIST_G, N_LISTS };
 enum { SLOT_QUEUE_HEAD = N_LISTS, SLOT_STATUS = N_LISTS + 1, SLOT_GROUP_QUEUE = N_LISTS + 2, SLOT_GROUP_QUEUE_POS = N_LISTS + 3,
        SLOT_N_LONG = N_LISTS + 4, SLOT_TILES_DONE = N_LISTS + 5, SLOT_TR_TICKET = N_LISTS + 6,
        SLOT_QUEUE_SUB = N_LISTS + 7 /* 8 words */, SLOT_G_TICKET = N_LISTS + 15, SLOT_PACK_TICKETS = N_LISTS + 16 /* 64 words */,
-       N_SMALL_SLOTS = N_LISTS + 16 + 64 };
+       SLOT_G_HITS16 = N_LISTS + 80 /* hits the G tier found, in sixteens (saturating) */,
+       N_SMALL_SLOTS = N_LISTS + 16 + 64 + 1 };
 static_assert(N_SMALL_SLOTS <= 256, "the finalize step zeroes one slot per thread");
 // one entry: everything a tier needs to start on a query, in one 16-byte load
 struct alignas(16) WorkItem {
@@ -406,6 +407,8 @@ struct CountParams {
     kaamer_counters *fin_out;
     uint32_t *fin_small, *fin_status_out;
     unsigned long long *fin_cursors;
+    uint32_t *fin_slot_scale;   // table capacity scale for the next batch (count_group.hip.inc: table_slots_for)
+    uint32_t fin_scale_cap, fin_scale_margin;
 };
 
 // G-tier hit lists live after the table layout's total
@@ -744,7 +747,8 @@ struct NullTable {
 // workgroup made the kernel 30x slower).
 template <bool IN_FLIGHT>
 __device__ __forceinline__ void finalize_body(unsigned long long *replicas, kaamer_counters *out, uint32_t *small_state,
-                                              uint32_t *status_out, unsigned long long *cursors)
+                                              uint32_t *status_out, unsigned long long *cursors, uint32_t *slot_scale = nullptr,
+                                              uint32_t scale_cap = 16u, uint32_t margin_q4 = 30u)
 {
     // 256 threads: lane <-> replica, wave w sums counters w, w+4, ...
     static_assert(CTR_REPLICAS == 64, "one replica per lane");
@@ -757,11 +761,29 @@ __device__ __forceinline__ void finalize_body(unsigned long long *replicas, kaam
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
         if (lane == 0) ((unsigned long long *)out)[c] = s;
     }
-    if (threadIdx.x == 0)
+    unsigned long long g_hits = 0;
+    if (threadIdx.x == 0) {
         *status_out = IN_FLIGHT ? __hip_atomic_load(&small_state[SLOT_STATUS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : small_state[SLOT_STATUS];
+        g_hits = 16ull * (IN_FLIGHT ? __hip_atomic_load(&small_state[SLOT_G_HITS16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : small_state[SLOT_G_HITS16]);
+    }
     __syncthreads();
     if (threadIdx.x < N_SMALL_SLOTS) small_state[threadIdx.x] = 0;
     if (threadIdx.x < 3) cursors[threadIdx.x * CURSOR_STRIDE] = 0;  // G-tier tail cursor, G arena cursors (count, positions)
+    // the next batch's counting tables: 1.5 x SizeInKmer x (distinct proteins per k-mer of THIS batch, + 20 %), never
+    // below 1.5 x SizeInKmer, never more than the hit arrays were provisioned for (scale_cap, from the workspace's sizes)
+    if (slot_scale && threadIdx.x == 0) {
+        // (written by this workgroup, above).  Queries that left their LDS table are left out on both sides: a few
+        // monsters with tens of thousands of hits (a skewed database) say nothing about the tables of the others
+        const unsigned long long nq = out->n_queries, ovf = out->n_overflow < nq ? out->n_overflow : nq;
+        const unsigned long long hits = out->n_hits > g_hits ? out->n_hits - g_hits : 0ull;
+        const unsigned long long lookups = nq ? out->n_lookup / nq * (nq - ovf) + out->n_lookup % nq * (nq - ovf) / nq : 0ull;
+        if (lookups) {
+            unsigned long long t = (hits * margin_q4 + lookups - 1ull) / lookups;   // sixteenths: 16 x hits / lookups x margin / 16
+            if (t < 16ull) t = 16ull;
+            if (t > scale_cap) t = scale_cap;
+            *slot_scale = (uint32_t)t;
+        }
+    }
 }
 
 #ifndef G_MIN_BLOCKS
@@ -1115,6 +1137,8 @@ __global__ __launch_bounds__(64 * G_WAVES, G_MIN_BLOCKS) void count_global_kerne
     if (lane == 0) {
         const uint32_t rep = blockIdx.x * WAVES + wv;
         add_counter(p.counters, rep, CTR_HITS, tot_hits);
+        // (what the queries that left their LDS tables found: the next batch's table scale is worked out without them)
+        if (tot_hits) atomicAdd(p.queue_head + (SLOT_G_HITS16 - SLOT_QUEUE_HEAD), (uint32_t)((tot_hits + 15ull) >> 4 > 0x0FFFFFFFull ? 0x0FFFFFFFull : (tot_hits + 15ull) >> 4));
         add_counter(p.counters, rep, CTR_POST, f_post);
         add_counter(p.counters, rep, CTR_LISTS, f_lists);
         add_counter(p.counters, rep, CTR_LIST_IDS, f_lids);
@@ -1134,7 +1158,7 @@ __global__ __launch_bounds__(64 * G_WAVES, G_MIN_BLOCKS) void count_global_kerne
         }
         __syncthreads();
         if (s_last) {
-            finalize_body<true>(p.counters, p.fin_out, p.fin_small, p.fin_status_out, p.fin_cursors);
+            finalize_body<true>(p.counters, p.fin_out, p.fin_small, p.fin_status_out, p.fin_cursors, p.fin_slot_scale, p.fin_scale_cap, p.fin_scale_margin);
         }
     }
 }
@@ -1361,9 +1385,9 @@ __global__ __launch_bounds__(256) void gather_hits_kernel(const uint32_t *d_nq, 
 }
 
 __global__ void finalize_kernel(unsigned long long *replicas, kaamer_counters *out, uint32_t *small_state,
-                                uint32_t *status_out, unsigned long long *cursors)
+                                uint32_t *status_out, unsigned long long *cursors, uint32_t *slot_scale, uint32_t scale_cap, uint32_t margin_q4)
 {
-    finalize_body<false>(replicas, out, small_state, status_out, cursors);
+    finalize_body<false>(replicas, out, small_state, status_out, cursors, slot_scale, scale_cap, margin_q4);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1415,6 +1439,10 @@ struct kaamer_workspace {
     uint2 *d_sched;                     // schedule_kernel: ticket -> (group, first query)
     uint64_t *d_group_start;            // layout_kernel: slot at which the group's first table starts
     unsigned long long *d_lay_total;    // total table slots of the batch
+    uint32_t *d_slot_scale;             // table capacity scale of the next batch, sixteenths (finalize_body)
+    uint32_t slot_scale_cap;            // the largest scale the hit arrays were provisioned for
+    uint32_t slot_scale_margin;         // sixteenths: tables of (hits per k-mer) x this
+    bool dense_tables;                  // the last finished batch left a table scale of 2 or more: ORF packs take the larger arena
     uint32_t *d_n_sched;
     // post-steps (kaamer_topn_device), allocated on first use
     uint32_t topn_k;
@@ -1577,7 +1605,7 @@ void kaamer_workspace_free(kaamer_workspace *ws)
                      ws->d_tmp_meta, ws->d_orf_aa, ws->d_starts_alt, ws->d_q_cnt, ws->d_csr_off, ws->d_c_pid, ws->d_c_km, ws->d_c_fp,
                      ws->d_pool_cursor, ws->d_lists, ws->d_list_counts, ws->d_status_out, ws->d_qinfo, ws->d_slots,
                      ws->d_slot_off, ws->d_group_first, ws->d_n_groups, ws->d_pos_words, ws->d_pos_base, ws->d_pos_off, ws->d_pos_bits, ws->d_g_keys,
-                     ws->d_counter_replicas, ws->d_counters, ws->d_bsum, ws->d_chain, ws->d_tr_chain, ws->d_sched, ws->d_n_sched, ws->d_group_start, ws->d_lay_total, ws->d_top_cnt, ws->d_top_pid, ws->d_top_km, ws->d_top_fp, ws->d_top_trim, ws->d_top_start, ws->d_top_size, ws->d_rep_flag, ws->d_rep_aalen, ws->d_rep_query, ws->d_rep_pid, ws->d_rep_km, ws->d_rep_fp, ws->d_rep_trim, ws->d_rep_rank, ws->d_rep_eoff, ws->d_rep_aoff, ws->d_rep_off, ws->d_rep_q, ws->d_rep_aa, ws->d_hit_off,
+                     ws->d_counter_replicas, ws->d_counters, ws->d_bsum, ws->d_chain, ws->d_tr_chain, ws->d_sched, ws->d_n_sched, ws->d_group_start, ws->d_lay_total, ws->d_slot_scale, ws->d_top_cnt, ws->d_top_pid, ws->d_top_km, ws->d_top_fp, ws->d_top_trim, ws->d_top_start, ws->d_top_size, ws->d_rep_flag, ws->d_rep_aalen, ws->d_rep_query, ws->d_rep_pid, ws->d_rep_km, ws->d_rep_fp, ws->d_rep_trim, ws->d_rep_rank, ws->d_rep_eoff, ws->d_rep_aoff, ws->d_rep_off, ws->d_rep_q, ws->d_rep_aa, ws->d_hit_off,
                      ws->d_hit_pid, ws->d_hit_km, ws->d_hit_fp, ws->d_x_dst_off, ws->d_x_src_off, ws->d_x_nq_owned, ws->d_x_pid, ws->d_x_km, ws->d_x_fp, ws->d_x_ent_off, ws->d_x_tiles };
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (ws->ev) {
@@ -1731,6 +1759,24 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     if (!rc) rc = dev_alloc(&ws->d_sched, ws->groups_cap);
     if (!rc) rc = dev_alloc(&ws->d_group_start, ws->groups_cap);
     if (!rc) rc = dev_alloc(&ws->d_lay_total, 1);
+    if (!rc) rc = dev_alloc(&ws->d_slot_scale, 4);
+    if (!rc) {
+        const uint32_t one = SLOT_SCALE_ONE;
+        if (hipMemcpy(ws->d_slot_scale, &one, 4, hipMemcpyHostToDevice) != hipSuccess) rc = kaamer_fail(KAAMER_E_HIP, "workspace init");
+        // tables of a batch as large as the workspace allows, at scale s (sixteenths): 1.5 x s/16 x positions + 64 per
+        // query; they may take 70 % of the hit arrays (the G tier's lists come after them)
+        const double room = 0.7 * (double)ws->sparse_cap - 64.0 * (double)ws->q_cap;
+        double cap = room > 0 ? room * 16.0 / (1.5 * (double)(ws->pos_cap ? ws->pos_cap : 1)) : 16.0;
+        if (getenv("KAAMER_SLOT_SCALE_MAX")) cap = atof(getenv("KAAMER_SLOT_SCALE_MAX")) * 16.0;
+        ws->slot_scale_cap = cap < 16.0 ? 16u : cap > 128.0 ? 128u : (uint32_t)cap;
+        ws->slot_scale_margin = 30u;   // x 1.9: the hits of a query spread around the batch's mean (measured on DB-UR-lite: 1.2 -> 22.8 ms per
+                                       // batch, 1.5 -> 13.9, 1.9 -> 11.9; profiles/r03_dense_database.md)
+        ws->dense_tables = getenv("KAAMER_PACK_LONG") != nullptr;
+        if (getenv("KAAMER_SLOT_MARGIN")) ws->slot_scale_margin = (uint32_t)(atof(getenv("KAAMER_SLOT_MARGIN")) * 16.0);
+        if (getenv("KAAMER_WS_TRACE"))
+            fprintf(stderr, "[kaamer workspace] pos_cap %llu q_cap %u hit_cap %llu sparse_cap %llu slot_scale_cap %u/16\n", (unsigned long long)ws->pos_cap,
+                    ws->q_cap, (unsigned long long)ws->hit_cap, (unsigned long long)ws->sparse_cap, ws->slot_scale_cap);
+    }
     if (!rc) rc = dev_alloc(&ws->d_n_sched, 1);
     if (!rc) rc = dev_alloc(&ws->d_n_groups, 1);
 
@@ -1871,6 +1917,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         pl.slots = ws->d_slots; pl.bshift = ws->pack_shift; pl.cshift = ws->pack_shift >= GRP_SHIFT ? 9u : 7u;
         pl.no_sched = ws->use_group ? 0u : 1u;
         pl.d_total = ws->d_lay_total;
+        pl.slot_scale = ws->d_slot_scale;
         const uint32_t tiles = (uint32_t)(((uint64_t)n_seqs + 1 + PL_TILE - 1) / PL_TILE);
         hipLaunchKernelGGL(prep_layout_schedule_kernel, dim3(tiles), dim3(LAY_THREADS), 0, s, pl);
     } else {
@@ -1930,7 +1977,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         hipLaunchKernelGGL(orf_order_long_kernel, dim3((unsigned)(n_long_bound < (uint64_t)ws->n_cu * 32 ? (n_long_bound + 3) / 4 + 1 : (uint64_t)ws->n_cu * 8)), dim3(256), 0, s,
                            ws->d_tmp_meta, tp.off_orf, ws->d_long_seq, tp.n_long, ws->d_q, ws->d_nq);
         hipLaunchKernelGGL(prep_orf_kernel, dim3(ws->n_cu * 4), dim3(pb), 0, s, ws->d_q, ws->d_nq, ws->d_valid, ws->d_n_pos,
-                           ws->d_qinfo, ws->d_slots, ws->d_hit_off, ws->d_q_cnt);
+                           ws->d_qinfo, ws->d_slots, ws->d_hit_off, ws->d_q_cnt, ws->d_slot_scale);
         residues = ws->d_orf_aa;
         pos_bound = ws->aa_cap;
         nq_bound = ws->q_cap;
@@ -2006,7 +2053,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
             // longer sequences (mixed read lengths, contigs): the arena that holds tables of up to 576 slots, or 66 000
             // ORFs of a 1 M mixed-read batch went to the G tier (measured: 8.19 -> 6.73 ms for the counting stage of
             // that batch, while the 150-nt batch loses 0.4 ms with the larger arena)
-            const bool long_orfs = seq_bytes > 200ull * (n_seqs ? n_seqs : 1u);
+            const bool long_orfs = seq_bytes > 200ull * (n_seqs ? n_seqs : 1u) || ws->dense_tables;
             uint64_t g2 = gb;
             if (long_orfs) {
                 if (g2 > (uint64_t)ws->pack_grid_long) g2 = ws->pack_grid_long;
@@ -2026,6 +2073,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     if (fused_finalize) {
         pg.fin_out = ws->d_counters; pg.fin_small = ws->d_list_counts; pg.fin_status_out = ws->d_status_out;
         pg.fin_cursors = ws->d_pool_cursor;
+        pg.fin_slot_scale = ws->d_slot_scale; pg.fin_scale_cap = ws->slot_scale_cap; pg.fin_scale_margin = ws->slot_scale_margin;
     }
     hipLaunchKernelGGL(count_global_kernel, dim3(g_grid), dim3(64 * G_WAVES), 0, s, pg);
     if (ws->compact) launch_compaction(ws, nq_bound, status, s);
@@ -2069,7 +2117,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     }
     if (!fused_finalize)
         hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->d_counter_replicas, ws->d_counters, ws->d_list_counts,
-                           ws->d_status_out, ws->d_pool_cursor);
+                           ws->d_status_out, ws->d_pool_cursor, ws->d_slot_scale, ws->slot_scale_cap, ws->slot_scale_margin);
     if (timed) HIPCHK(hipEventRecord(ev[4], s));
     HIPCHK(hipGetLastError());
     ws->clean = true;  // everything up to finalize is enqueued
@@ -2150,7 +2198,7 @@ static int merge_device_impl(kaamer_workspace *ws, const uint64_t *d_ent_off, co
     hipLaunchKernelGGL(merge_global_kernel, dim3(g_grid), dim3(256), 0, s, pg);
     if (ws->compact) launch_compaction(ws, nq_bound, status, s);
     hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(256), 0, s, ws->d_counter_replicas, ws->d_counters, ws->d_list_counts,
-                       ws->d_status_out, ws->d_pool_cursor);
+                       ws->d_status_out, ws->d_pool_cursor, (uint32_t *)nullptr, 16u, 16u);   // (a merge looks nothing up: the scale stays)
     HIPCHK(hipGetLastError());
     ws->clean = true;
     ws->last_was_merge = true;
@@ -2411,6 +2459,16 @@ int kaamer_topn_device(kaamer_workspace *ws, const kaamer_topn_opts *opts, void 
     return KAAMER_OK;
 }
 
+// What the device's finalize step left as the next batch's table scale, worked out again on the host from the same
+// counters: from a scale of 2 on, ORF batches take the pack kernel with the larger arena (tables of 200-500 slots).
+static void ws_note_density(kaamer_workspace *ws, const kaamer_counters &c)
+{
+    if (!c.n_lookup || getenv("KAAMER_PACK_LONG")) return;
+    unsigned long long t = (c.n_hits * ws->slot_scale_margin + c.n_lookup - 1ull) / c.n_lookup;
+    if (t > ws->slot_scale_cap) t = ws->slot_scale_cap;
+    ws->dense_tables = t >= 2u * SLOT_SCALE_ONE;
+}
+
 int kaamer_workspace_finish(kaamer_workspace *ws, void *stream, kaamer_counters *out)
 {
     if (!ws) return kaamer_fail(KAAMER_E_ARG, "workspace_finish: bad argument");
@@ -2421,6 +2479,7 @@ int kaamer_workspace_finish(kaamer_workspace *ws, void *stream, kaamer_counters 
     kaamer_counters c;
     HIPCHK(hipMemcpy(&c, ws->d_counters, sizeof c, hipMemcpyDeviceToHost));
     if (out) *out = c;
+    if (!ws->last_was_merge) ws_note_density(ws, c);
     if (status) ws->clean = false;  // an aborted batch may leave per-batch state behind
     if (status & ST_POOL_FULL) return kaamer_fail(KAAMER_E_CAPACITY, "hit pool exhausted: raise workspace max_hits (now %llu)", (unsigned long long)ws->hit_cap);
     if (status & ST_LIST_FULL) return kaamer_fail(KAAMER_E_CAPACITY, "tier work list exhausted");

@@ -208,3 +208,42 @@ def test_device_topn_long_lists(klib, oracle, gpu_device):
             keep = oracle.filter_results(ekm, size, ratio, mink, maxr)
             assert cnt[i] == keep
             assert pid[i, :keep].tolist() == epid[:keep].tolist() and km[i, :keep].tolist() == ekm[:keep].tolist()
+
+
+def test_makedb_to_hit_entries_end_to_end(klib, oracle, gpu_device):
+    """The whole drop-in flow over the C ABI: database FASTA text -> kaamer_makedb_fasta (the reference's id rule,
+    inputFASTA.go:95-124: ids run on from the second record's, the last two records share one) -> the table built ON THE DEVICE
+    (kaamer_image_build_makedb_device) -> ProteinSearch -> FetchHitsInformation (search.go:454-470): every reported
+    Key resolves to the database record the reference's id rule gave that id, and the counts are the oracle's."""
+    from kaamer_amd import api, search, workload
+    db = workload.make_db(600, seed=77)
+    recs = workload.unpack(db)
+    fasta = "".join(">sp|P%05d|NAME_%d OS=Test organism GN=g%d\n%s\n" % (i, i, i, s.decode()) for i, s in enumerate(recs))
+    prot = api.Proteins.from_fasta(fasta.encode())
+    ids = np.asarray(prot.ids)
+    assert len(ids) == len(recs) and (np.diff(ids[:-1]) == 1).all() and ids[-1] == ids[-2]   # the id rule and its last-record quirk
+    img = prot.image(device=gpu_device)
+    assert img.stats() == prot.image().stats()                                           # device builder == host builder
+    ix = api.Index.from_image(img, gpu_device)
+    qs = workload.unpack(workload.make_protein_queries(db, 60, seed=78))
+    qtext = "".join(">query%d\n%s\n" % (i, s.decode()) for i, s in enumerate(qs))
+    res = search.FetchHitsInformation(search.ProteinSearch(ix, qtext, search.SearchOptions(MaxResults=5)), prot)
+    assert len(res) > 40
+    # the oracle over the same (sequence, id) pairs
+    oix = oracle.Index.from_proteins(recs, ids=ids.tolist())
+    by_id = {}
+    for s, i in zip(recs, ids.tolist()):
+        by_id.setdefault(i, s)          # two records under the last id: the table keeps the first (makedb.cpp)
+    for qr in res:
+        q = next(s for i, s in enumerate(qs) if "query%d" % i == qr["Query"]["Name"])
+        pid, km, _ = oix.search(q)
+        full = dict(zip(pid.tolist(), km.tolist()))
+        hits = qr["SearchResults"]["Hits"]
+        assert [h["Kmatch"] for h in hits] == km[:len(hits)].tolist()
+        assert set(qr["HitEntries"]) == {h["Key"] for h in hits}
+        for h in hits:
+            assert full[h["Key"]] == h["Kmatch"]
+            e = qr["HitEntries"][h["Key"]]
+            assert e["Length"] == len(e["Sequence"]) and e["EntryId"].startswith("sp|P")
+            if h["Key"] != int(ids[-1]):    # (the shared last id has two candidate records)
+                assert e["Sequence"].encode() == by_id[h["Key"]]
