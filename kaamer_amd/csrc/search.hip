@@ -1768,6 +1768,8 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
         const double room = 0.7 * (double)ws->sparse_cap - 64.0 * (double)ws->q_cap;
         double cap = room > 0 ? room * 16.0 / (1.5 * (double)(ws->pos_cap ? ws->pos_cap : 1)) : 16.0;
         if (getenv("KAAMER_SLOT_SCALE_MAX")) cap = atof(getenv("KAAMER_SLOT_SCALE_MAX")) * 16.0;
+        // (never above 8: at 3e9 residues on one device, 6.6 hits per k-mer, tables of 12 x 1.5 x SizeInKmer leave the pack
+        // kernel's arena and the batch takes 92 ms instead of 44; profiles/r03_dense_database.md)
         ws->slot_scale_cap = cap < 16.0 ? 16u : cap > 128.0 ? 128u : (uint32_t)cap;
         ws->slot_scale_margin = 30u;   // x 1.9: the hits of a query spread around the batch's mean (measured on DB-UR-lite: 1.2 -> 22.8 ms per
                                        // batch, 1.5 -> 13.9, 1.9 -> 11.9; profiles/r03_dense_database.md)
