@@ -250,6 +250,9 @@ typedef struct {
     kaamer_counters counters;
 } kaamer_batch_out;
 
+/* May be called from any number of threads on one index (the worker pool of
+ * search_protein.go:58-118): a call takes one of four slots -- workspace, staging,
+ * stream -- and callers beyond the slots wait for one. */
 int kaamer_search_batch(kaamer_index *ix, const kaamer_batch_in *in, kaamer_batch_out **out);
 void kaamer_batch_free(kaamer_batch_out *out);
 

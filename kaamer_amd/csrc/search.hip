@@ -79,6 +79,8 @@ struct HostSlot {
     uint8_t *d_seqs = nullptr;
     uint64_t *d_off = nullptr;
     size_t seq_cap = 0, off_cap = 0;
+    hipStream_t stream = nullptr;   // every slot works on its own stream
+    bool busy = false;              // (under kaamer_index::pool_mu)
 };
 
 // one in-flight call of the pipelined host-buffer boundary (host_top.hip.inc)
@@ -104,8 +106,9 @@ struct kaamer_index {
     kh_image_header hdr;
     kh_bucket *d_buckets;
     uint32_t *d_arena;
-    std::mutex host_mu;   // kaamer_search_batch (full hit lists) calls on one index are serialised
-    HostSlot host[1];     // its workspace and staging
+    // kaamer_search_batch (full hit lists): a call takes a free slot (workspace + staging + stream) and gives it back;
+    // callers beyond the slots wait for one.  Same pool lock as the slots below.
+    HostSlot host[4];
     // kaamer_submit_batch_top / kaamer_search_batch_top / kaamer_stream_*: a pool of slots, one per call in flight
     std::mutex pool_mu;
     std::condition_variable pool_cv;
@@ -1580,6 +1583,7 @@ void kaamer_index_close(kaamer_index *ix)
     if (!ix) return;
     (void)hipSetDevice(ix->device);
     for (HostSlot &h : ix->host) {
+        if (h.stream) (void)hipStreamDestroy(h.stream);
         if (h.ws) kaamer_workspace_free(h.ws);
         if (h.d_seqs) (void)hipFree(h.d_seqs);
         if (h.d_off) (void)hipFree(h.d_off);
@@ -2638,7 +2642,7 @@ static int host_slot_acquire(kaamer_index *ix, HostSlot &h, const kaamer_workspa
     return KAAMER_OK;
 }
 
-static int search_batch_once(kaamer_index *ix, const kaamer_batch_in *in, uint64_t max_hits, uint64_t g_slots,
+static int search_batch_once(kaamer_index *ix, HostSlot &slot, const kaamer_batch_in *in, uint64_t max_hits, uint64_t g_slots,
                              uint32_t max_queries, kaamer_batch_out **out)
 {
     const uint64_t seq_bytes = in->offsets[in->n_seqs];
@@ -2654,18 +2658,19 @@ static int search_batch_once(kaamer_index *ix, const kaamer_batch_in *in, uint64
     o.compact = 1u;  // the host form is CSR
     o.max_pos_words = max_hits * 8;
     o.max_queries = max_queries;
-    HostSlot &slot = ix->host[0];
     int rc = host_slot_acquire(ix, slot, o, seq_bytes, in->n_seqs);
     if (rc) return rc;
+    if (!slot.stream) HIPCHK(hipStreamCreateWithFlags(&slot.stream, hipStreamNonBlocking));
     kaamer_workspace *ws = slot.ws;
     uint8_t *d_seqs = slot.d_seqs;
     uint64_t *d_off = slot.d_off;
     batch_out_owner *bo = nullptr;
-    hipStream_t s = nullptr;
+    hipStream_t s = slot.stream;
     kaamer_device_result dr;
     kaamer_counters c;
     uint32_t nq = 0;
-    uint64_t n_hits = 0;
+    uint64_t n_hits = 0, n_words = 0, n_sa = 0;
+    unsigned long long n_aa = 0;
     hipError_t e;
     e = hipMemcpyAsync(d_seqs, in->seqs, (size_t)seq_bytes, hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(d_off, in->offsets, ((size_t)in->n_seqs + 1) * 8, hipMemcpyHostToDevice, s);
@@ -2676,37 +2681,41 @@ static int search_batch_once(kaamer_index *ix, const kaamer_batch_in *in, uint64
     if (rc) goto done;
     bo = new (std::nothrow) batch_out_owner();
     if (!bo) { rc = kaamer_fail(KAAMER_E_NOMEM, "batch_out"); goto done; }
-    e = hipMemcpy(&nq, dr.d_n_queries, 4, hipMemcpyDeviceToHost);
+    // every copy on the slot's own stream (a plain hipMemcpy goes through the null stream, where concurrent callers
+    // would queue behind each other); the host waits where it needs a value to size the next copy
+    e = hipMemcpyAsync(&nq, dr.d_n_queries, 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e == hipSuccess) { bo->q.resize(nq); bo->hit_off.resize((size_t)nq + 1); bo->hit_cnt.resize((size_t)nq + 1); }
-    if (e == hipSuccess && nq) e = hipMemcpy(bo->hit_cnt.data(), dr.d_hit_cnt, (size_t)nq * 4, hipMemcpyDeviceToHost);
-    if (e == hipSuccess && nq) e = hipMemcpy(bo->q.data(), dr.d_q, (size_t)nq * sizeof(kaamer_query_meta), hipMemcpyDeviceToHost);
-    if (e == hipSuccess) e = hipMemcpy(bo->hit_off.data(), dr.d_hit_off, ((size_t)nq + 1) * 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && nq) e = hipMemcpyAsync(bo->hit_cnt.data(), dr.d_hit_cnt, (size_t)nq * 4, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && nq) e = hipMemcpyAsync(bo->q.data(), dr.d_q, (size_t)nq * sizeof(kaamer_query_meta), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(bo->hit_off.data(), dr.d_hit_off, ((size_t)nq + 1) * 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && ws->want_positions) e = hipMemcpyAsync(&n_words, ws->d_pos_base + nq, sizeof n_words, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && ws->nucleotide) {
+        const size_t cap6 = (size_t)ws->max_seqs * 6;
+        e = hipMemcpyAsync(&n_aa, ws->d_n_pos, sizeof n_aa, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(&n_sa, ws->d_off3 + 2 * (cap6 + 1) + (size_t)in->n_seqs * 6, sizeof n_sa, hipMemcpyDeviceToHost, s);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e == hipSuccess) {
         n_hits = bo->hit_off[nq];
         if (!bo->pid.resize(n_hits) || !bo->km.resize(n_hits) || !bo->fp.resize(n_hits)) e = hipErrorOutOfMemory;
         if (e == hipSuccess && n_hits) {
-            e = hipMemcpy(bo->pid.data(), dr.d_hit_pid, n_hits * 4, hipMemcpyDeviceToHost);
-            if (e == hipSuccess) e = hipMemcpy(bo->km.data(), dr.d_hit_kmatch, n_hits * 4, hipMemcpyDeviceToHost);
-            if (e == hipSuccess) e = hipMemcpy(bo->fp.data(), dr.d_hit_first_pos, n_hits * 4, hipMemcpyDeviceToHost);
+            e = hipMemcpyAsync(bo->pid.data(), dr.d_hit_pid, n_hits * 4, hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipMemcpyAsync(bo->km.data(), dr.d_hit_kmatch, n_hits * 4, hipMemcpyDeviceToHost, s);
+            if (e == hipSuccess) e = hipMemcpyAsync(bo->fp.data(), dr.d_hit_first_pos, n_hits * 4, hipMemcpyDeviceToHost, s);
         }
     }
     if (e == hipSuccess && ws->want_positions) {
-        uint64_t n_words = 0;
-        e = hipMemcpy(&n_words, ws->d_pos_base + nq, sizeof n_words, hipMemcpyDeviceToHost);
-        if (e == hipSuccess) { bo->pos_off.resize(n_hits + 1); bo->pos_bits.resize(n_words + 1); }
-        if (e == hipSuccess && n_hits) e = hipMemcpy(bo->pos_off.data(), dr.d_pos_off, n_hits * 8, hipMemcpyDeviceToHost);
-        if (e == hipSuccess && n_words) e = hipMemcpy(bo->pos_bits.data(), dr.d_pos_bits, n_words * 8, hipMemcpyDeviceToHost);
+        bo->pos_off.resize(n_hits + 1); bo->pos_bits.resize(n_words + 1);
+        if (n_hits) e = hipMemcpyAsync(bo->pos_off.data(), dr.d_pos_off, n_hits * 8, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && n_words) e = hipMemcpyAsync(bo->pos_bits.data(), dr.d_pos_bits, n_words * 8, hipMemcpyDeviceToHost, s);
     }
     if (e == hipSuccess && ws->nucleotide) {
-        unsigned long long n_aa = 0;
-        uint64_t n_sa = 0;
-        e = hipMemcpy(&n_aa, ws->d_n_pos, sizeof n_aa, hipMemcpyDeviceToHost);
-        const size_t cap6 = (size_t)ws->max_seqs * 6;
-        if (e == hipSuccess) e = hipMemcpy(&n_sa, ws->d_off3 + 2 * (cap6 + 1) + (size_t)in->n_seqs * 6, sizeof n_sa, hipMemcpyDeviceToHost);
-        if (e == hipSuccess) { bo->orf_aa.resize(n_aa + 1); bo->starts_alt.resize(n_sa + 1); }
-        if (e == hipSuccess && n_aa) e = hipMemcpy(bo->orf_aa.data(), dr.d_orf_aa, n_aa, hipMemcpyDeviceToHost);
-        if (e == hipSuccess && n_sa) e = hipMemcpy(bo->starts_alt.data(), dr.d_starts_alt, n_sa * sizeof(int32_t), hipMemcpyDeviceToHost);
+        bo->orf_aa.resize(n_aa + 1); bo->starts_alt.resize(n_sa + 1);
+        if (n_aa) e = hipMemcpyAsync(bo->orf_aa.data(), dr.d_orf_aa, n_aa, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess && n_sa) e = hipMemcpyAsync(bo->starts_alt.data(), dr.d_starts_alt, n_sa * sizeof(int32_t), hipMemcpyDeviceToHost, s);
     }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) { rc = kaamer_fail(KAAMER_E_HIP, "D2H: %s", hipGetErrorString(e)); goto done; }
     memset(&bo->pub, 0, sizeof bo->pub);
     bo->pub.n_queries = nq;
@@ -2730,15 +2739,30 @@ int kaamer_search_batch(kaamer_index *ix, const kaamer_batch_in *in, kaamer_batc
 {
     if (!ix || !in || !out || !in->offsets || (in->n_seqs && !in->seqs)) return kaamer_fail(KAAMER_E_ARG, "search_batch: bad argument");
     *out = nullptr;
-    std::lock_guard<std::mutex> lock(ix->host_mu);
     HIPCHK(hipSetDevice(ix->device));
+    // a free slot (one whose workspace already serves this kind of batch, if there is one); callers beyond the slots wait
+    HostSlot *slot = nullptr;
+    {
+        std::unique_lock<std::mutex> lock(ix->pool_mu);
+        for (;;) {
+            for (HostSlot &h : ix->host)
+                if (!h.busy && (!slot || (h.ws && h.opts.seq_type == in->seq_type && !(slot->ws && slot->opts.seq_type == in->seq_type)))) slot = &h;
+            if (slot) break;
+            ix->pool_cv.wait(lock);
+        }
+        slot->busy = true;
+    }
+    struct Release {
+        kaamer_index *ix; HostSlot *h;
+        ~Release() { { std::lock_guard<std::mutex> lock(ix->pool_mu); h->busy = false; } ix->pool_cv.notify_all(); }
+    } release{ ix, slot };
     // The hit count of a batch is data dependent: start from a generous estimate and
     // enlarge on KAAMER_E_CAPACITY (the device reports it; results are never partial).
     uint64_t max_hits = in->offsets[in->n_seqs] * 8 + 65536, g_slots = 0;
     uint32_t max_queries = 0;
     const bool nucl = in->seq_type == KAAMER_NUCLEOTIDE || in->seq_type == KAAMER_READS;
     for (int attempt = 0;; attempt++) {
-        const int rc = search_batch_once(ix, in, max_hits, g_slots, max_queries, out);
+        const int rc = search_batch_once(ix, *slot, in, max_hits, g_slots, max_queries, out);
         if (rc != KAAMER_E_CAPACITY || attempt >= 6) return rc;
         max_hits *= 4;
         g_slots = g_slots ? g_slots * 4 : (128ull << 20);

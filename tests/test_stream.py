@@ -107,3 +107,51 @@ def test_concurrent_callers_and_tickets(klib, oracle, gpu_device):
     tk = [ix.submit_top(packed=batches[j], seq_type=kinds[j]) for j in (0, 6, 1, 7)]
     for t, j in sorted(zip(tk, (0, 6, 1, 7)), key=lambda x: -x[1]):
         check(t.wait(), exp[j])
+
+
+@pytest.mark.gpu
+def test_concurrent_full_hit_list_callers(klib, oracle, gpu_device):
+    """kaamer_search_batch (full hit lists, positions on request) from eight threads at once on one index: every call
+    takes a slot of its own (workspace, staging, stream) -- more threads than slots, protein and read batches mixed, so
+    slots are re-made for the other kind while others run -- and every result equals the oracle's"""
+    import threading
+    from kaamer_amd import abi, api, workload
+    db = workload.make_db(1200, seed=14)
+    ix = api.Index.from_image(api.Image.from_proteins(packed=db), gpu_device)
+    oix = oracle.Index.from_proteins(None, packed=db)
+    batches = [workload.make_protein_queries(db, 40 + 9 * i, seed=120 + i) for i in range(5)] + \
+              [workload.make_reads(db, 120 + 10 * i, seed=140 + i) for i in range(3)]
+    kinds = [abi.PROTEIN] * 5 + [abi.READS] * 3
+
+    def expected(q, kind):
+        out = []
+        for s in workload.unpack(q):
+            for seq in ([s] if kind == abi.PROTEIN else [o["seq"] for o in oracle.get_orfs(s)]):
+                if oracle.size_in_kmer(seq) < 7:
+                    out.append(({}, {}))
+                    continue
+                pid, km, pos = oix.search(seq, want_positions=True)
+                out.append((dict(zip(pid.tolist(), km.tolist())), {int(p): int(np.argmax(pos[j])) for j, p in enumerate(pid)}))
+        return out
+
+    exp = [expected(q, k) for q, k in zip(batches, kinds)]
+    errors = []
+
+    def worker(i):
+        try:
+            for r in range(3):
+                j = (i + 3 * r) % len(batches)
+                res = ix.search(packed=batches[j], seq_type=kinds[j], want_positions=(i + r) % 4 == 0)
+                assert res.n_queries == len(exp[j]), (res.n_queries, len(exp[j]))
+                for q, (hits, fp) in enumerate(exp[j]):
+                    assert res.hits(q) == hits, (j, q)
+                    assert res.first_pos(q) == fp, (j, q)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(8)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errors, errors[:3]

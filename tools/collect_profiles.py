@@ -31,6 +31,10 @@ def counter_sums(d, counter):
     """kernel name -> (sum over dispatches, dispatches)"""
     acc = {}
     for r in csv.DictReader(open(one(d + "/*/*_counter_collection.csv"))):
+        # (the table is built on the device once per process -- builder_device.hip's kernels and rocPRIM's: not part of a batch)
+        # nor are the fills: the steady state of a workspace has none, they initialise the build's tables and the workspaces
+        if "bd_" in r["Kernel_Name"] or "rocprim" in r["Kernel_Name"] or "fillBuffer" in r["Kernel_Name"]:
+            continue
         if r["Counter_Name"] == counter:
             a = acc.setdefault(r["Kernel_Name"], [0.0, 0])
             a[0] += float(r["Counter_Value"])
