@@ -2571,7 +2571,7 @@ void *pinned_get(size_t bytes, size_t *cap)
 void pinned_put(void *p, size_t cap)
 {
     std::lock_guard<std::mutex> lock(g_pinned.mu);
-    if (g_pinned.free_list.size() < 12) g_pinned.free_list.emplace_back(p, cap);
+    if (g_pinned.free_list.size() < 32) g_pinned.free_list.emplace_back(p, cap);   // (four full-list callers hold twelve arrays at once)
     else (void)hipHostFree(p);
 }
 
