@@ -452,14 +452,6 @@ def main():
         six.close()
         return rep
 
-    leg = None
-    if (world > 1 or args.sharded_leg >= 2) and not sharded_mode and args.sharded_leg:
-        try:
-            leg = sharded_leg()
-        except Exception as e:   # the headline line must survive a failure of the secondary leg
-            leg = {"error": repr(e)}
-        log("sharded leg: %s" % json.dumps(leg))
-
     # work of the timed region = sum over the launches of their batch's exact counters
     n_timed = n_launch - first_timed
     times_run = [len(range((b - first_timed) % n_distinct, n_timed, n_distinct)) for b in range(n_distinct)]
@@ -587,7 +579,28 @@ def main():
     }
     if exch is not None:
         out["exchange"] = exch
-    if leg is not None:
+    # ---- the secondary sharded leg, after the headline is complete: whatever happens in it -- an exception on one rank, a
+    # collective that never returns -- the headline line is printed.  A watchdog per rank ends the process when the leg
+    # has not come back in time (a hung collective cannot be interrupted from Python); rank 0 prints the line first.
+    if (world > 1 or args.sharded_leg >= 2) and not sharded_mode and args.sharded_leg:
+        import threading
+        leg_done = threading.Event()
+
+        def leg_watchdog():
+            if leg_done.wait(240.0):
+                return
+            log("sharded leg: no answer after 240 s, giving up on it")
+            if rank == 0:
+                out["sharded_leg"] = {"error": "timeout: the leg did not return within 240 s"}
+                emit(json.dumps(out))
+            os._exit(0)
+        threading.Thread(target=leg_watchdog, daemon=True).start()
+        try:
+            leg = sharded_leg()
+        except Exception as e:   # the headline line must survive a failure of the secondary leg
+            leg = {"error": repr(e)}
+        leg_done.set()
+        log("sharded leg: %s" % json.dumps(leg))
         out["sharded_leg"] = leg
 
     if rank == 0:
@@ -733,8 +746,15 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(oix, q, seconds=args.cpu_seconds, kind="reads" if nucl else "protein")
         emit(json.dumps(out))
     if world > 1 or sharded_mode:
+        # (a rank that left the sharded leg on an error never reaches this barrier together with the others: the line is
+        # out by now, so a barrier that does not come back within a minute just ends the process)
+        import threading
+        bye = threading.Timer(60.0, lambda: os._exit(0))
+        bye.daemon = True
+        bye.start()
         dist.barrier()
         dist.destroy_process_group()
+        bye.cancel()
 
 
 if __name__ == "__main__":
