@@ -269,6 +269,13 @@ typedef struct {
     uint32_t max_seqs;       /* most input sequences per batch                 */
     uint32_t max_queries;    /* most queries (ORFs) per batch; 0 = derive      */
     uint64_t max_hits;       /* most (query,protein) pairs per batch; 0=derive */
+                             /* (from the input size).  It also bounds how far */
+                             /* the per-query counting tables may grow on a     */
+                             /* database where a k-mer meets several proteins:  */
+                             /* every batch leaves the next one's table scale   */
+                             /* (hits per k-mer x 1.9, <= 8) on the device, cut */
+                             /* to what these arrays hold -- provision ~4 hits  */
+                             /* per k-mer of the batch on such a database       */
     uint64_t g_tier_slots;   /* HBM counting-table slots for queries whose     */
                              /* distinct hits exceed the on-chip tiers; 0 = def*/
     int32_t seq_type;        /* KAAMER_PROTEIN, or KAAMER_NUCLEOTIDE / READS   */
