@@ -2296,10 +2296,12 @@ int kaamer_exchange_pack(kaamer_workspace *ws, const kaamer_exchange_layout *L, 
         hipLaunchKernelGGL(x_scan_top_kernel<0>, dim3(1), dim3(X_BLOCK), 0, s, x);
         hipLaunchKernelGGL(x_scan_apply_kernel<0>, dim3(x.n_tiles, L->world), dim3(X_BLOCK), 0, s, x);
     }
-    uint32_t gb = (ws->q_cap + 15) / 16;  // 16 queries per 256-thread block (X_GROUP lanes each)
+    const bool wide = ws->q_cap <= X_WIDE_QUERIES;   // few queries with long lists: a wave per query
+    uint32_t gb = wide ? (ws->q_cap + 3) / 4 : (ws->q_cap + 15) / 16;  // 4 / 16 queries per 256-thread block
     if (gb > (uint32_t)ws->n_cu * 8) gb = (uint32_t)ws->n_cu * 8;
     if (gb < 1) gb = 1;
-    hipLaunchKernelGGL(x_pack_copy_kernel, dim3(gb), dim3(256), 0, s, x);
+    if (wide) hipLaunchKernelGGL(x_pack_copy_kernel<X_GROUP_WIDE>, dim3(gb), dim3(256), 0, s, x);
+    else hipLaunchKernelGGL(x_pack_copy_kernel<X_GROUP>, dim3(gb), dim3(256), 0, s, x);
     HIPCHK(hipGetLastError());
     return KAAMER_OK;
 }
@@ -2356,10 +2358,12 @@ int kaamer_exchange_merge(kaamer_workspace *ws, const kaamer_exchange_layout *L,
         hipLaunchKernelGGL(x_scan_top_kernel<1>, dim3(1), dim3(X_BLOCK), 0, s, x);
         hipLaunchKernelGGL(x_scan_apply_kernel<1>, dim3(x.n_tiles, L->world + 1), dim3(X_BLOCK), 0, s, x);
     }
-    uint32_t gb = (L->q_cap + 15) / 16;
+    const bool wide = (uint64_t)L->q_cap * L->world <= X_WIDE_QUERIES;
+    uint32_t gb = wide ? (L->q_cap + 3) / 4 : (L->q_cap + 15) / 16;
     if (gb > (uint32_t)ws->n_cu * 8) gb = (uint32_t)ws->n_cu * 8;
     if (gb < 1) gb = 1;
-    hipLaunchKernelGGL(x_unpack_copy_kernel, dim3(gb), dim3(256), 0, s, x);
+    if (wide) hipLaunchKernelGGL(x_unpack_copy_kernel<X_GROUP_WIDE>, dim3(gb), dim3(256), 0, s, x);
+    else hipLaunchKernelGGL(x_unpack_copy_kernel<X_GROUP>, dim3(gb), dim3(256), 0, s, x);
     HIPCHK(hipGetLastError());
     return merge_device_impl(ws, ws->d_x_ent_off, ws->d_x_pid, ws->d_x_km, ws->d_x_fp, L->q_cap, ws->d_x_nq_owned, m_cap, stream, out);
 }
