@@ -777,8 +777,11 @@ __device__ __forceinline__ void finalize_body(unsigned long long *replicas, kaam
     if (slot_scale && threadIdx.x == 0) {
         // (written by this workgroup, above).  Queries that left their LDS table are left out on both sides: a few
         // monsters with tens of thousands of hits (a skewed database) say nothing about the tables of the others
-        const unsigned long long nq = out->n_queries, ovf = out->n_overflow < nq ? out->n_overflow : nq;
-        const unsigned long long hits = out->n_hits > g_hits ? out->n_hits - g_hits : 0ull;
+        // -- unless most queries went there: then they ARE the typical ones, and everything counts
+        const unsigned long long nq = out->n_queries;
+        const bool typical = 2ull * out->n_overflow > nq;
+        const unsigned long long ovf = typical ? 0ull : (out->n_overflow < nq ? out->n_overflow : nq);
+        const unsigned long long hits = typical ? out->n_hits : (out->n_hits > g_hits ? out->n_hits - g_hits : 0ull);
         const unsigned long long lookups = nq ? out->n_lookup / nq * (nq - ovf) + out->n_lookup % nq * (nq - ovf) / nq : 0ull;
         if (lookups) {
             unsigned long long t = (hits * margin_q4 + lookups - 1ull) / lookups;   // sixteenths: 16 x hits / lookups x margin / 16

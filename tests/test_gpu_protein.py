@@ -296,3 +296,48 @@ def test_position_bitmaps_g_tier(klib, oracle, gpu_device):
             assert len(pid) == 3000
         for i, p in enumerate(pid.tolist()):
             assert got[p].tolist() == pos[i].tolist(), (qi, p)
+
+
+def test_counting_tables_follow_the_previous_batch(klib, oracle, gpu_device):
+    """A database whose proteins are built from a small pool of segments: a query meets more proteins than it has k-mers,
+    so tables of 1.5 x SizeInKmer slots crowd and queries leave them for the G tier.  The finalize step of a batch leaves
+    the next batch's table scale on the device (hits per k-mer x 1.9, within what max_hits provisioned): the second run
+    of the same batch sends fewer queries there, and the results are the oracle's every time."""
+    import torch
+    from kaamer_amd import api
+    rng = np.random.default_rng(12)
+    alpha = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
+    pool = [bytes(alpha[rng.integers(0, 20, 25)]) for _ in range(40)]
+    db = [b"".join(pool[int(k)] for k in rng.integers(0, 40, 10)) for _ in range(1500)]
+    img = api.Image.from_proteins(db)
+    ix = api.Index.from_image(img, gpu_device)
+    oix = oracle.Index.from_proteins(db)
+    seqs = [db[int(i)] for i in rng.integers(0, len(db), 120)]
+    exp = _oracle_hits(oix, oracle, seqs)
+    sizes = sum(oracle.size_in_kmer(s) for s in seqs)
+    assert sum(len(h) for h, _ in exp) > 2 * sizes          # more than two distinct proteins per k-mer
+    buf, offs = api.pack_sequences(seqs)
+    d_buf = torch.from_numpy(buf).cuda()
+    d_off = torch.from_numpy(offs.view(np.int64)).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(ws):
+        r = ws.search_device(d_buf.data_ptr(), d_off.data_ptr(), len(seqs), len(buf), stream=st)
+        c = ws.finish(st)
+        hit_off = _from_ptr(r.d_hit_off, len(seqs) + 1, np.uint64)
+        hit_cnt = _from_ptr(r.d_hit_cnt, len(seqs), np.uint32)
+        n = int(r.hit_capacity)
+        pid, km, fp = (_from_ptr(x, n, np.uint32) for x in (r.d_hit_pid, r.d_hit_kmatch, r.d_hit_first_pos))
+        for i, (h, f) in enumerate(exp):
+            a, b = int(hit_off[i]), int(hit_off[i]) + int(hit_cnt[i])
+            assert dict(zip(pid[a:b].tolist(), km[a:b].tolist())) == h, i
+            assert dict(zip(pid[a:b].tolist(), fp[a:b].tolist())) == f, i
+        return c["n_overflow"]
+
+    roomy = api.Workspace(ix, len(buf), len(seqs), first_pos=1, max_hits=40 * len(buf))
+    ovf = [run(roomy) for _ in range(3)]
+    assert ovf[0] > 0 and ovf[1] < ovf[0] and ovf[2] <= ovf[1], ovf
+    # a workspace with default sizes: whatever scale its hit arrays allow, the results are the same
+    plain = api.Workspace(ix, len(buf), len(seqs), first_pos=1)
+    ovf_p = [run(plain) for _ in range(2)]
+    assert ovf_p[0] == ovf[0] and ovf_p[1] <= ovf_p[0]
