@@ -477,8 +477,9 @@ int kaamer_rccl_alltoall(void *nccl_comm, const void *d_send, void *d_recv, uint
 /* keys it owns, every owner (query q: shard q mod n_shards) pulls its blocks     */
 /* with peer copies over xGMI, merges, runs the post-steps; the reported queries  */
 /* come back in batch order, exactly what kaamer_search_batch_top returns on an   */
-/* unsharded index.  No communicator, no second process.  One batch at a time     */
-/* per handle (calls are serialised).                                            */
+/* unsharded index.  No communicator, no second process.  Any number of threads   */
+/* may call on one handle: a call takes one of three sets of per-shard            */
+/* workspaces, buffers and streams; callers beyond the sets wait for one.         */
 /* ------------------------------------------------------------------------- */
 typedef struct kaamer_sharded_index kaamer_sharded_index;
 int kaamer_index_open_sharded(const char *const *paths, const int *devices, uint32_t n_shards, kaamer_sharded_index **out);

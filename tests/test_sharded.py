@@ -598,3 +598,44 @@ def test_single_process_sharded_handle(klib, oracle, gpu_device, reads):
     with pytest.raises(abi.KaamerError) as e:
         api.ShardedIndex.from_images([api.Image.from_proteins(packed=db, shard=1, n_shards=2)] * 2, [gpu_device] * 2)
     assert e.value.code == abi.E_FORMAT
+
+
+@pytest.mark.gpu
+def test_sharded_handle_concurrent_callers(klib, oracle, gpu_device):
+    """Several threads call kaamer_sharded_search_batch_top on ONE handle at once (the reference server's goroutines against
+    one set of stores, api/server.go:47-65): every call takes a free set of per-shard workspaces and streams -- more
+    threads than sets, protein and read batches mixed -- and every result equals the unsharded call's."""
+    import threading
+    from kaamer_amd import abi, api, workload
+    db = workload.make_db(500, seed=16)
+    ix1 = api.Index.from_image(api.Image.from_proteins(packed=db), gpu_device)
+    world = 2
+    sx = api.ShardedIndex.from_images([api.Image.from_proteins(packed=db, shard=r, n_shards=world) for r in range(world)], [gpu_device] * world)
+    batches = [workload.make_protein_queries(db, 50 + 11 * i, seed=60 + i) for i in range(4)] + \
+              [workload.make_reads(db, 100 + 20 * i, seed=80 + i) for i in range(2)]
+    kinds = [abi.PROTEIN] * 4 + [abi.READS] * 2
+    refs = [ix1.search_top(packed=q, seq_type=k) for q, k in zip(batches, kinds)]
+    errors = []
+
+    def same(top, ref):
+        assert top.n_queries == ref.n_queries
+        assert top.rep_query.tolist() == ref.rep_query.tolist()
+        assert top.top_off.tolist() == ref.top_off.tolist()
+        assert top.top_pid.tolist() == ref.top_pid.tolist() and top.top_kmatch.tolist() == ref.top_kmatch.tolist()
+        assert top.trim.tolist() == ref.trim.tolist()
+
+    def worker(i):
+        try:
+            for r in range(3):
+                j = (i + 2 * r) % len(batches)
+                same(sx.search_top(packed=batches[j], seq_type=kinds[j]), refs[j])
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(6)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    sx.close()
+    assert not errors, errors[:3]
