@@ -110,33 +110,48 @@ __global__ __launch_bounds__(BD_THREADS) void bd_windows_kernel(const uint8_t *_
                                                                  uint64_t total_res, uint32_t shard, uint32_t n_shards,
                                                                  uint64_t *__restrict__ pairs, uint64_t cap, BuildStats *st)
 {
-    // positions are absolute (as in off[]); seqs is indexed with pos - origin
+    // A thread owns BD_PER_THREAD CONSECUTIVE positions: their residues are 22 bytes read once (a wave reads 1 KB in one
+    // piece) and coded once, the windows slide over them, and the protein of a position is the previous position's or
+    // one of the next (one binary search per thread, inside the tile's protein range).  Positions are absolute (as in
+    // off[]); seqs is indexed with pos - origin and has 16 bytes of slack behind the last residue.
+    __shared__ uint8_t s_lut[256];
+    for (uint32_t i = threadIdx.x; i < 256; i += BD_THREADS) s_lut[i] = (uint8_t)kh_residue_code((uint8_t)i);
+    __syncthreads();
     const uint64_t base = origin + (uint64_t)blockIdx.x * BD_TILE;
     const uint64_t end = origin + total_res;
     const uint64_t tile_last = (base + BD_TILE < end ? base + BD_TILE : end) - 1;
     const uint32_t p_lo = protein_of(off, 0, n_prot, base);
     const uint32_t p_hi = protein_of(off, p_lo, n_prot, tile_last) + 1;
+    const uint64_t pos0 = base + (uint64_t)threadIdx.x * BD_PER_THREAD;
     uint32_t keys[BD_PER_THREAD], pid[BD_PER_THREAD];
     uint32_t okmask = 0, mine = 0;
 #pragma unroll
-    for (uint32_t k = 0; k < BD_PER_THREAD; k++) {
-        const uint64_t pos = base + k * BD_THREADS + threadIdx.x;
-        bool ok = false;
-        keys[k] = 0; pid[k] = 0;
-        if (pos + KAAMER_KMER_SIZE <= end) {
-            const uint32_t p = protein_of(off, p_lo, p_hi, pos);
-            if (pos + KAAMER_KMER_SIZE <= off[p + 1]) {                       // inputFASTA.go:228,245
-                const uint8_t *s = seqs + (pos - origin);
-                const uint32_t key = kh_key_from_codes(kh_residue_code(s[0]), kh_residue_code(s[1]), kh_residue_code(s[2]),
-                                                       kh_residue_code(s[3]), kh_residue_code(s[4]), kh_residue_code(s[5]),
-                                                       kh_residue_code(s[6]));
+    for (uint32_t k = 0; k < BD_PER_THREAD; k++) { keys[k] = 0; pid[k] = 0; }
+    if (pos0 + KAAMER_KMER_SIZE <= end) {
+        uint8_t c[BD_PER_THREAD + 8];
+        {
+            uint32_t w[(BD_PER_THREAD + 8) / 4];
+            __builtin_memcpy(w, seqs + (pos0 - origin), sizeof w);
+#pragma unroll
+            for (uint32_t i = 0; i < BD_PER_THREAD + 8; i++) c[i] = s_lut[(w[i >> 2] >> (8u * (i & 3u))) & 255u];
+        }
+        uint32_t p = protein_of(off, p_lo, p_hi, pos0);
+        uint64_t p_end = off[p + 1];
+        uint32_t id = ids ? ids[p] : p;                                    // inputTSV.go:141-142
+#pragma unroll
+        for (uint32_t k = 0; k < BD_PER_THREAD; k++) {
+            const uint64_t pos = pos0 + k;
+            while (pos >= p_end && p + 1 < n_prot) { p++; p_end = off[p + 1]; id = ids ? ids[p] : p; }   // (empty proteins too)
+            bool ok = false;
+            if (pos + KAAMER_KMER_SIZE <= p_end && pos < end) {              // inputFASTA.go:228,245
+                const uint32_t key = kh_key_from_codes(c[k], c[k + 1], c[k + 2], c[k + 3], c[k + 4], c[k + 5], c[k + 6]);
                 ok = n_shards <= 1 || kh_shard_of(key, n_shards) == shard;
                 keys[k] = key;
-                pid[k] = ids ? ids[p] : p;                                     // inputTSV.go:141-142
+                pid[k] = id;
             }
+            okmask |= (uint32_t)ok << k;
+            mine += ok;
         }
-        okmask |= (uint32_t)ok << k;
-        mine += ok;
     }
     // one reservation per wave
     const uint32_t lane = threadIdx.x & 63u;
@@ -391,7 +406,7 @@ int kaamer_build_on_device(const uint8_t *seqs, const uint64_t *offsets, const u
     uint64_t n_emit = 0;
     if (total_res >= KAAMER_KMER_SIZE) {
         DevMem d_seqs, d_off, d_ids;
-        BD_HIP(d_seqs.alloc(total_res + 16));
+        BD_HIP(d_seqs.alloc(total_res + 32));   // (a thread of the emit kernel reads 24 bytes from its first position)
         BD_HIP(d_off.alloc(((size_t)n_proteins + 1) * 8));
         BD_HIP(hipMemcpy(d_seqs.p, seqs + origin, total_res, hipMemcpyHostToDevice));
         BD_HIP(hipMemcpy(d_off.p, offsets, ((size_t)n_proteins + 1) * 8, hipMemcpyHostToDevice));
