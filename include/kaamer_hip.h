@@ -537,6 +537,12 @@ int32_t kaamer_set_best_start_codon(const uint32_t *kmatch_sorted, const uint32_
 /* rule; FASTQ sequence lines must match ^[ATGCNatgcn]+$).                     */
 /* ------------------------------------------------------------------------- */
 typedef struct kaamer_reads kaamer_reads;
+/* `text` is the bytes of the file.  Bytes that start with the gzip signature (what the reference's
+ * http.DetectContentType calls application/x-gzip, search.go:255-263, 361-366) are inflated first: every member of the
+ * stream (Go's gzip.Reader is multistream); a stream that breaks off or is damaged reads as what inflated before that
+ * (the reference's scanner stops at the read error and processes what it got); a first header that is no gzip header
+ * is KAAMER_E_FORMAT (gzip.NewReader fails: no queries).  The same holds for kaamer_makedb_embl / _gbk
+ * (inputEMBL.go:76-84, inputGBK.go:75-83); the FASTA and TSV makedb readers have no gzip branch in the reference. */
 int kaamer_parse_fasta(const char *text, uint64_t len, kaamer_reads **out);
 int kaamer_parse_fastq(const char *text, uint64_t len, kaamer_reads **out);
 uint32_t kaamer_reads_count(const kaamer_reads *r);

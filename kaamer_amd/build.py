@@ -39,7 +39,7 @@ def build(force=False, verbose=False):
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     cmd = [_hipcc(), "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall",
            "-Wno-unused-function"] + os.environ.get("KAAMER_EXTRA_CFLAGS", "").split() + \
-          ["-o", LIB + ".tmp"] + srcs + ["-lpthread"]
+          ["-o", LIB + ".tmp"] + srcs + ["-lpthread", "-lz"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -9,6 +9,8 @@
 // In the Go integration these stay the reference's own Go code.
 #include "kaamer_internal.h"
 
+#include <zlib.h>
+
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -61,6 +63,67 @@ void push_record(kaamer_reads *r, const std::string &seq, const std::string &nam
 
 }  // namespace
 
+bool kaamer_is_gzip(const char *text, uint64_t len)
+{
+    return len >= 3 && (uint8_t)text[0] == 0x1F && (uint8_t)text[1] == 0x8B && (uint8_t)text[2] == 0x08;
+}
+
+int kaamer_gunzip(const char *text, uint64_t len, std::string *out)
+{
+    out->clear();
+    z_stream z;
+    memset(&z, 0, sizeof z);
+    if (inflateInit2(&z, 16 + MAX_WBITS) != Z_OK) return kaamer_fail(KAAMER_E_NOMEM, "gzip: inflateInit2");
+    z.next_in = (Bytef *)const_cast<char *>(text);
+    uint64_t left = len;
+    bool first_header_seen = false;
+    std::string buf(1u << 20, '\0');
+    for (;;) {
+        if (z.avail_in == 0 && left) {
+            const uInt take = left > (1u << 30) ? (1u << 30) : (uInt)left;
+            z.avail_in = take;
+            left -= take;
+        }
+        z.next_out = (Bytef *)&buf[0];
+        z.avail_out = (uInt)buf.size();
+        const int rc = inflate(&z, Z_NO_FLUSH);
+        const size_t got = buf.size() - z.avail_out;
+        if (got) { out->append(buf.data(), got); first_header_seen = true; }
+        if (rc == Z_STREAM_END) {
+            first_header_seen = true;
+            if (z.avail_in == 0 && left == 0) break;          // the last member ended with the input
+            // another member follows (gzip.Reader multistream); bytes that are not a gzip header end the text here
+            const Bytef *next = z.next_in;
+            const uInt avail = z.avail_in;
+            if (inflateReset(&z) != Z_OK) break;
+            z.next_in = const_cast<Bytef *>(next);
+            z.avail_in = avail;
+            continue;
+        }
+        if (rc == Z_OK) continue;
+        if (rc == Z_BUF_ERROR && z.avail_in == 0 && left == 0) break;   // the stream breaks off: what was read stays
+        break;                                                           // damaged data: the same
+    }
+    inflateEnd(&z);
+    if (!first_header_seen && out->empty()) {
+        // (an empty member is fine; a first header that is no gzip header is gzip.NewReader's error)
+        z_stream t;
+        memset(&t, 0, sizeof t);
+        bool ok = false;
+        if (inflateInit2(&t, 16 + MAX_WBITS) == Z_OK) {
+            Bytef sink[64];
+            t.next_in = (Bytef *)const_cast<char *>(text);
+            t.avail_in = len > 4096 ? 4096u : (uInt)len;
+            t.next_out = sink; t.avail_out = sizeof sink;
+            const int rc = inflate(&t, Z_NO_FLUSH);
+            ok = rc == Z_OK || rc == Z_STREAM_END || rc == Z_BUF_ERROR;
+            inflateEnd(&t);
+        }
+        if (!ok) return kaamer_fail(KAAMER_E_FORMAT, "gzip: invalid header");
+    }
+    return KAAMER_OK;
+}
+
 extern "C" {
 
 // GetQueriesFasta, search.go:222-322, on decompressed text.  Reference behaviours kept:
@@ -70,6 +133,12 @@ extern "C" {
 int kaamer_parse_fasta(const char *text, uint64_t len, kaamer_reads **out)
 {
     if (!out || (!text && len)) return kaamer_fail(KAAMER_E_ARG, "parse_fasta: bad argument");
+    std::string inflated;   // (search.go:259-263, 361-366: gzipped input)
+    if (kaamer_is_gzip(text, len)) {
+        const int zrc = kaamer_gunzip(text, len, &inflated);
+        if (zrc) return zrc;
+        text = inflated.data(); len = inflated.size();
+    }
     kaamer_reads *r = new (std::nothrow) kaamer_reads();
     if (!r) return kaamer_fail(KAAMER_E_NOMEM, "parse_fasta");
     r->offsets.push_back(0);
@@ -102,6 +171,12 @@ int kaamer_parse_fasta(const char *text, uint64_t len, kaamer_reads **out)
 int kaamer_parse_fastq(const char *text, uint64_t len, kaamer_reads **out)
 {
     if (!out || (!text && len)) return kaamer_fail(KAAMER_E_ARG, "parse_fastq: bad argument");
+    std::string inflated;   // (search.go:259-263, 361-366: gzipped input)
+    if (kaamer_is_gzip(text, len)) {
+        const int zrc = kaamer_gunzip(text, len, &inflated);
+        if (zrc) return zrc;
+        text = inflated.data(); len = inflated.size();
+    }
     kaamer_reads *r = new (std::nothrow) kaamer_reads();
     if (!r) return kaamer_fail(KAAMER_E_NOMEM, "parse_fastq");
     r->offsets.push_back(0);

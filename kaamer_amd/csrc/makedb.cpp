@@ -374,6 +374,12 @@ int makedb_flat(const char *text, uint64_t len, bool gbk, kaamer_proteins **out)
 {
     if (!out || (!text && len)) return kaamer_fail(KAAMER_E_ARG, "makedb_%s: bad argument", gbk ? "gbk" : "embl");
     *out = nullptr;
+    std::string inflated;   // (inputEMBL.go:76-84, inputGBK.go:75-83: gzipped input; the FASTA and TSV readers have no such branch)
+    if (kaamer_is_gzip(text, len)) {
+        const int zrc = kaamer_gunzip(text, len, &inflated);
+        if (zrc) return zrc;
+        text = inflated.data(); len = inflated.size();
+    }
     kaamer_proteins *r = new_proteins();
     if (!r) return kaamer_fail(KAAMER_E_NOMEM, "makedb");
     if (gbk) r->feature_names = { "ProteinName", "Organism", "FullTaxonomy" };       // GBK_DEF_FTS, inputGBK.go:41

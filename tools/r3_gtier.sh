@@ -5,7 +5,7 @@ mkdir -p build gpurun_out
 one() { name=$1; flags=$2
   lib=""
   if [ -n "$flags" ]; then
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-function $flags -o build/libkaamer_$name.so kaamer_amd/csrc/search.hip kaamer_amd/csrc/builder.cpp kaamer_amd/csrc/host_search.cpp kaamer_amd/csrc/makedb.cpp -lpthread 2> gpurun_out/g_$name.build.log || { tail -3 gpurun_out/g_$name.build.log; return 1; }
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-function $flags -o build/libkaamer_$name.so kaamer_amd/csrc/search.hip kaamer_amd/csrc/builder.cpp kaamer_amd/csrc/host_search.cpp kaamer_amd/csrc/makedb.cpp -lpthread -lz 2> gpurun_out/g_$name.build.log || { tail -3 gpurun_out/g_$name.build.log; return 1; }
     lib=$PWD/build/libkaamer_$name.so
   fi
   KAAMER_LIB=$lib python bench.py --db zipf --steps 3 --warmup 1 --no-cpu-baseline --check 0 > gpurun_out/g_$name.json 2> gpurun_out/g_$name.log || { tail -3 gpurun_out/g_$name.log; return 1; }
