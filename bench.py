@@ -115,6 +115,34 @@ def cpu_baseline(oix, queries, seconds=12.0, threads=None, kind="protein"):
             "queries_per_s": nqd / dt}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: this process -- which has not imported torch nor touched the GPU --
+    starts N fresh children, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run sets
+    them), relays rank 0's JSON line and returns non-zero if any rank did.  Nothing is re-executed in place."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    line = procs[0].stdout.read().decode()
+    rcs = [p.wait() for p in procs]
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print("[bench] ranks failed (rank, exit code): %s" % bad, file=sys.stderr, flush=True)
+        if line.strip():
+            print("[bench] rank 0 printed: %s" % line.strip()[:2000], file=sys.stderr, flush=True)
+        return 1
+    sys.stdout.write(line)
+    sys.stdout.flush()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -173,6 +201,8 @@ def main():
                     help="1: finish every batch with the hit lists packed in query order (one more scan + copy pass); "
                          "0 (default): each query's list stays where the search kernel wrote it (offset + count per query)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     # stdout carries ONE line, the JSON: everything else a library prints there (RCCL's version banner at
     # communicator creation, for one) goes to stderr
@@ -215,13 +245,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:   # a line whose n_gpus is not what was asked for would read as a flat scaling curve
+        log("error: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+        sys.exit(2)
     sharded_mode = args.mode == "sharded"
     if world > 1 or sharded_mode:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
     torch.cuda.set_device(local_rank)
 
     from kaamer_amd import abi, api, workload
@@ -300,17 +332,21 @@ def main():
         if final_batch is not None:   # leave the results of this batch in the workspaces (the parity check reads them)
             final = searcher.step(bufs[final_batch].data_ptr(), offs[final_batch].data_ptr(), args.queries, sizes[final_batch], tstream)
             searcher.finish(tstream)
-        L = searcher.layout
+        L = searcher.wire   # the layout of the last batch: blocks sized from what an earlier batch needed, not the capacity
         bw, W = int(L.block_words), int(L.world)
-        hdr = torch.stack([searcher.send[d * bw:d * bw + 4] for d in range(W)]).cpu().numpy()   # [entries, status, nq, owned]
+        hdr = torch.stack([searcher.send[d * bw:d * bw + 8] for d in range(W)]).cpu().numpy()   # [entries, status, nq, owned, need, max need, -, -]
         words = 3 if searcher.ws_first_pos else 2
-        payload = int(sum(4 * (4 + int(h[3]) + words * int(h[0])) for h in hdr))
+        payload = int(sum(4 * (8 + int(h[3]) + words * int(h[0])) for h in hdr))
+        wire = W * 4 * bw
         return {"transport": searcher.transport,
                 "rccl_comm_ranks": searcher.comm.world if searcher.comm is not None else None,
                 "phase_ms_per_batch": {k: ph[k] / ph["batches"] for k in sharded.PHASES},
                 "phase_batches": ph["batches"],
-                "wire_bytes_per_rank_per_batch": W * searcher.block_bytes,      # fixed-size blocks: what the all-to-all moves
-                "payload_bytes_per_rank_per_batch": payload,                     # headers + counts + entries actually packed
+                "wire_bytes_per_rank_per_batch": wire,          # what the all-to-all moves: world equal blocks of this batch's layout
+                "payload_bytes_per_rank_per_batch": payload,     # headers + counts + entries actually packed
+                "wire_over_payload": wire / max(payload, 1),
+                "capacity_bytes_per_rank": W * searcher.block_bytes,   # what the buffers could hold (never travels as such)
+                "adaptive_blocks": bool(searcher.adaptive),
                 "block_entry_capacity": int(L.e_cap), "entries_packed_per_block": [int(h[0]) for h in hdr]}, final
 
     if sharded_mode:
@@ -364,22 +400,39 @@ def main():
     wss[0].set_timing(args.time_every)  # sampled: an event record idles the stream for a few microseconds
     wss[0].reset_timers()
 
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t_start = time.perf_counter()
-    first_timed = n_launch
-    last = None
-    for _ in range(args.steps):
-        for _ in range(args.batches_per_step):
-            last = launch(n_launch)
-            n_launch += 1
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t_start
+    def timed_region():
+        nonlocal n_launch
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0_ = time.perf_counter()
+        first_ = n_launch
+        last_ = None
+        for _ in range(args.steps):
+            for _ in range(args.batches_per_step):
+                last_ = launch(n_launch)
+                n_launch += 1
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        return time.perf_counter() - t0_, first_, last_
+
+    elapsed, first_timed, last = timed_region()
+    try:
+        finish_all()
+    except abi.KaamerError as e:
+        # sharded mode sizes the exchange blocks from what earlier batches needed: a batch that outgrew its blocks fails on
+        # every rank alike (the overflow is in every header).  The measurement is then repeated with capacity-sized
+        # blocks and says so in `exchange.adaptive_blocks`; anything else is an error
+        if not (sharded_mode and e.code == abi.E_CAPACITY and searcher.adaptive):
+            raise
+        log("a batch outgrew its adaptive exchange blocks: timing again with capacity-sized blocks")
+        searcher.adaptive = False
+        launch(n_launch); n_launch += 1
+        finish_all()
+        elapsed, first_timed, last = timed_region()
+        finish_all()
     last_batch = (n_launch - 1) % n_distinct
-    finish_all()
     tm = wss[0].kernel_ms_sum()
     n_calls = max(tm["calls"], 1)
     # with several batches in flight the kernels of neighbouring batches share the device: their durations in the
@@ -593,7 +646,7 @@ def main():
             if rank == 0:
                 out["sharded_leg"] = {"error": "timeout: the leg did not return within 240 s"}
                 emit(json.dumps(out))
-            os._exit(0)
+            os._exit(3)   # a collective never returned: the launcher must see a failure
         threading.Thread(target=leg_watchdog, daemon=True).start()
         try:
             leg = sharded_leg()
@@ -749,7 +802,7 @@ def main():
         # (a rank that left the sharded leg on an error never reaches this barrier together with the others: the line is
         # out by now, so a barrier that does not come back within a minute just ends the process)
         import threading
-        bye = threading.Timer(60.0, lambda: os._exit(0))
+        bye = threading.Timer(60.0, lambda: os._exit(3))   # the final barrier hung: not a success
         bye.daemon = True
         bye.start()
         dist.barrier()

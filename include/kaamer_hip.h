@@ -15,7 +15,13 @@
  *   - input pointers are borrowed for the duration of the call only (cgo rule);
  *   - outputs of the host-buffer calls are library-owned until the matching
  *     *_free call;
- *   - plain pointers and sizes only, no C++ or torch types.
+ *   - plain pointers and sizes only, no C++ or torch types;
+ *   - cgo safety: NO STRUCT PASSED TO THE LIBRARY NEEDS TO CONTAIN A CALLER POINTER.  Every host-buffer call has a
+ *     *_flat form that takes the caller's buffers as direct arguments (cgo pins a Go pointer passed as an argument
+ *     for the duration of the call; a Go pointer stored inside a struct that is itself passed by pointer is a
+ *     run-time panic, "cgo argument has Go pointer to unpinned Go pointer").  The struct forms (kaamer_batch_in) are
+ *     for C / C++ / ctypes callers.  kaamer_topn_opts' pointer fields are device / library handles (NULL from a host
+ *     caller), never caller memory.
  */
 #ifndef KAAMER_HIP_H
 #define KAAMER_HIP_H
@@ -27,7 +33,7 @@
 extern "C" {
 #endif
 
-#define KAAMER_ABI_VERSION 3
+#define KAAMER_ABI_VERSION 4
 #define KAAMER_KMER_SIZE 7 /* pkg/search/search.go:45, pkg/makedb/makedb.go:30 */
 
 typedef enum {
@@ -254,6 +260,9 @@ typedef struct {
  * search_protein.go:58-118): a call takes one of four slots -- workspace, staging,
  * stream -- and callers beyond the slots wait for one. */
 int kaamer_search_batch(kaamer_index *ix, const kaamer_batch_in *in, kaamer_batch_out **out);
+/* the same call with the caller's buffers as direct arguments (the form a cgo shim binds, see the conventions above) */
+int kaamer_search_batch_flat(kaamer_index *ix, const uint8_t *seqs, const uint64_t *offsets, uint32_t n_seqs,
+                             int32_t seq_type, int32_t want_positions, kaamer_batch_out **out);
 void kaamer_batch_free(kaamer_batch_out *out);
 
 /* ------------------------------------------------------------------------- */
@@ -402,6 +411,18 @@ void kaamer_batch_top_free(kaamer_batch_top *out);
 typedef struct kaamer_ticket kaamer_ticket;
 int kaamer_submit_batch_top(kaamer_index *ix, const kaamer_batch_in *in, const kaamer_topn_opts *top, kaamer_ticket **ticket);
 int kaamer_wait_batch_top(kaamer_ticket *ticket, kaamer_batch_top **out);
+/* A ticket nobody will wait for (an error between submit and wait on the caller's side): lets the batch run out, drops
+ * its result and gives the slot back.  Without it the slot stays busy for good; kaamer_index_close waits for every
+ * slot to be given back. */
+void kaamer_ticket_discard(kaamer_ticket *ticket);
+/* cgo-safe forms: the caller's buffers and SearchOptions.MinKRatio / MinKMatch / MaxResults (search.go:56-71) as direct
+ * arguments; best_start_codon follows from seq_type as in the struct forms. */
+int kaamer_search_batch_top_flat(kaamer_index *ix, const uint8_t *seqs, const uint64_t *offsets, uint32_t n_seqs,
+                                 int32_t seq_type, double min_k_ratio, int64_t min_k_match, uint32_t max_results,
+                                 kaamer_batch_top **out);
+int kaamer_submit_batch_top_flat(kaamer_index *ix, const uint8_t *seqs, const uint64_t *offsets, uint32_t n_seqs,
+                                 int32_t seq_type, double min_k_ratio, int64_t min_k_match, uint32_t max_results,
+                                 kaamer_ticket **ticket);
 
 /* Streaming (BASELINE configs[4]: reads streamed host -> GPU with double-buffered copies): a FIFO of batches with
  * fixed options.  push copies chunk i + 1 and starts it while chunk i is still being searched; pop returns the
@@ -409,6 +430,8 @@ int kaamer_wait_batch_top(kaamer_ticket *ticket, kaamer_batch_top **out);
  * stream's own chunks: pop first.  One thread per stream; several streams may share an index. */
 typedef struct kaamer_stream kaamer_stream;
 int kaamer_stream_open(kaamer_index *ix, int32_t seq_type, const kaamer_topn_opts *top, kaamer_stream **out);
+int kaamer_stream_open_flat(kaamer_index *ix, int32_t seq_type, double min_k_ratio, int64_t min_k_match,
+                            uint32_t max_results, kaamer_stream **out);
 int kaamer_stream_push(kaamer_stream *st, const uint8_t *seqs, const uint64_t *offsets, uint32_t n_seqs);
 int kaamer_stream_pop(kaamer_stream *st, kaamer_batch_top **out);
 uint32_t kaamer_stream_pending(const kaamer_stream *st);
@@ -448,9 +471,23 @@ typedef struct {
                            /* world blocks                                       */
 } kaamer_exchange_layout;
 
-/* max_queries: the search workspace's query capacity (kaamer_workspace_query_capacity) */
+/* max_queries: the search workspace's query capacity (kaamer_workspace_query_capacity).  This is the CAPACITY layout:
+ * send / receive buffers hold world * block_words words of it. */
 int kaamer_exchange_layout_init(uint32_t world, uint32_t rank, uint32_t max_queries,
                                 uint64_t max_entries_per_peer, kaamer_exchange_layout *out);
+/* The layout of ONE batch inside the same buffers: blocks for n_queries queries of the batch and entries_per_block
+ * partial entries (both cut to the capacity layout).  What the all-to-all moves is world blocks of THIS layout's
+ * block_words, contiguous from the start of the buffers -- payload, not capacity.  Every rank must use the same layout
+ * for a batch: derive the two figures from kaamer_exchange_stats of an earlier batch (identical on all ranks) plus a
+ * margin; a batch that does not fit fails on every rank with KAAMER_E_CAPACITY and is repeated with the capacity
+ * layout. */
+int kaamer_exchange_layout_fit(const kaamer_exchange_layout *capacity, uint32_t n_queries, uint64_t entries_per_block,
+                               kaamer_exchange_layout *out);
+/* What the W block headers of an earlier kaamer_exchange_merge on `merge_ws` said, the same on every rank:
+ * out = { merge sequence number, queries of the batch, entries the largest block between ANY pair of ranks needed,
+ * non-zero if a block overflowed }.  back = 0: the last merge enqueued, 1: the one before.  Waits for that merge's
+ * header scan only (an event), not for the stream. */
+int kaamer_exchange_stats(kaamer_workspace *merge_ws, uint32_t back, uint64_t out[4]);
 uint32_t kaamer_workspace_query_capacity(const kaamer_workspace *ws);
 /* the last search of `search_ws` -> d_send[world * block_words] */
 int kaamer_exchange_pack(kaamer_workspace *search_ws, const kaamer_exchange_layout *layout,
@@ -489,6 +526,26 @@ uint32_t kaamer_sharded_index_shards(const kaamer_sharded_index *sx);
 void kaamer_sharded_index_close(kaamer_sharded_index *sx);
 int kaamer_sharded_search_batch_top(kaamer_sharded_index *sx, const kaamer_batch_in *in, const kaamer_topn_opts *top,
                                     kaamer_batch_top **out);
+/* The call in two halves (the worker pool of search_protein.go:58-118 against one sharded handle without a blocked
+ * thread per batch): submit takes a free set, copies the caller's buffers, enqueues the batch on every device and
+ * returns; wait collects the result (repeating the batch from the staging copy when a bound was too small) and gives
+ * the set back.  A ticket is waited for, or discarded, exactly once. */
+typedef struct kaamer_sharded_ticket kaamer_sharded_ticket;
+int kaamer_sharded_submit_batch_top(kaamer_sharded_index *sx, const kaamer_batch_in *in, const kaamer_topn_opts *top,
+                                    kaamer_sharded_ticket **ticket);
+int kaamer_sharded_wait_batch_top(kaamer_sharded_ticket *ticket, kaamer_batch_top **out);
+void kaamer_sharded_ticket_discard(kaamer_sharded_ticket *ticket);
+/* cgo-safe forms (see the conventions at the top) */
+int kaamer_sharded_search_batch_top_flat(kaamer_sharded_index *sx, const uint8_t *seqs, const uint64_t *offsets,
+                                         uint32_t n_seqs, int32_t seq_type, double min_k_ratio, int64_t min_k_match,
+                                         uint32_t max_results, kaamer_batch_top **out);
+int kaamer_sharded_submit_batch_top_flat(kaamer_sharded_index *sx, const uint8_t *seqs, const uint64_t *offsets,
+                                         uint32_t n_seqs, int32_t seq_type, double min_k_ratio, int64_t min_k_match,
+                                         uint32_t max_results, kaamer_sharded_ticket **ticket);
+/* The exchange of the last finished call on the handle's first set: out = { bytes of one (shard -> owner) block as it
+ * travelled, entries the largest block needed, queries of the batch, 1 if the blocks were sized from the previous
+ * call's need (payload) rather than the buffers' capacity }. */
+int kaamer_sharded_exchange_info(kaamer_sharded_index *sx, uint64_t out[4]);
 
 /* Waits for `stream`, copies the counters to the host and reports a deferred
  * KAAMER_E_CAPACITY if a device-side bound was exceeded during the batch. */

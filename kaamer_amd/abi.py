@@ -158,6 +158,8 @@ SYMBOLS = {
                                       C.c_void_p, C.POINTER(DeviceResult)]),
     "kaamer_exchange_layout_init": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(ExchangeLayout)]),
     "kaamer_workspace_query_capacity": (C.c_uint32, [C.c_void_p]),
+    "kaamer_exchange_layout_fit": (C.c_int, [C.POINTER(ExchangeLayout), C.c_uint32, C.c_uint64, C.POINTER(ExchangeLayout)]),
+    "kaamer_exchange_stats": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]),
     "kaamer_exchange_pack": (C.c_int, [C.c_void_p, C.POINTER(ExchangeLayout), C.c_void_p, C.c_void_p]),
     "kaamer_exchange_merge": (C.c_int, [C.c_void_p, C.POINTER(ExchangeLayout), C.c_void_p, C.c_void_p, C.POINTER(DeviceResult)]),
     "kaamer_rccl_alltoall": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
@@ -179,6 +181,23 @@ SYMBOLS = {
     "kaamer_stream_pop": (C.c_int, [C.c_void_p, C.c_void_p]),
     "kaamer_stream_pending": (C.c_uint32, [C.c_void_p]),
     "kaamer_stream_close": (None, [C.c_void_p]),
+    "kaamer_ticket_discard": (None, [C.c_void_p]),
+    # cgo-safe forms: (handle, seqs, offsets, n_seqs, seq_type, min_k_ratio, min_k_match, max_results, out)
+    "kaamer_search_batch_top_flat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_double,
+                                               C.c_int64, C.c_uint32, C.c_void_p]),
+    "kaamer_submit_batch_top_flat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_double,
+                                               C.c_int64, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "kaamer_search_batch_flat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_int32,
+                                           C.POINTER(C.POINTER(BatchOut))]),
+    "kaamer_stream_open_flat": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_int64, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "kaamer_sharded_submit_batch_top": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "kaamer_sharded_wait_batch_top": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "kaamer_sharded_ticket_discard": (None, [C.c_void_p]),
+    "kaamer_sharded_search_batch_top_flat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_double,
+                                                       C.c_int64, C.c_uint32, C.c_void_p]),
+    "kaamer_sharded_submit_batch_top_flat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_double,
+                                                       C.c_int64, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "kaamer_sharded_exchange_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "kaamer_workspace_reset_timers": (None, [C.c_void_p]),
     "kaamer_workspace_set_timing": (None, [C.c_void_p, C.c_uint32]),
     "kaamer_filter_results": (C.c_int64, [C.c_void_p, C.c_int64, C.c_int32, C.c_double, C.c_int64, C.c_int64]),

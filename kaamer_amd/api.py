@@ -371,42 +371,55 @@ class Index:
         abi.check(abi.lib().kaamer_index_get_stats(self._h, C.byref(s)))
         return s.as_dict()
 
-    def search(self, seqs=None, packed=None, seq_type=abi.PROTEIN, want_positions=False):
-        """Host-buffer form (kaamer_search_batch)."""
+    def search(self, seqs=None, packed=None, seq_type=abi.PROTEIN, want_positions=False, flat=True):
+        """Host-buffer form (kaamer_search_batch_flat: the entry point a cgo shim binds; flat=False: the struct form
+        kaamer_search_batch)."""
         buf, offs = packed if packed is not None else pack_sequences(seqs)
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
         offs = np.ascontiguousarray(offs, dtype=np.uint64)
-        bi = abi.BatchIn(buf.ctypes.data if len(buf) else None, offs.ctypes.data, len(offs) - 1, seq_type,
-                         int(want_positions))
         out = C.POINTER(abi.BatchOut)()
-        abi.check(abi.lib().kaamer_search_batch(self._h, C.byref(bi), C.byref(out)))
+        if flat:
+            abi.check(abi.lib().kaamer_search_batch_flat(self._h, buf.ctypes.data if len(buf) else None, offs.ctypes.data,
+                                                         len(offs) - 1, seq_type, int(want_positions), C.byref(out)))
+        else:
+            bi = abi.BatchIn(buf.ctypes.data if len(buf) else None, offs.ctypes.data, len(offs) - 1, seq_type,
+                             int(want_positions))
+            abi.check(abi.lib().kaamer_search_batch(self._h, C.byref(bi), C.byref(out)))
         return BatchResult(out)
 
-    def search_top(self, seqs=None, packed=None, seq_type=abi.PROTEIN, min_k_ratio=0.05, min_k_match=10, max_results=10):
-        """Host-buffer form that returns the reported hits only (kaamer_search_batch_top):
-        sortMapByValue order, SetBestStartCodon for nucleotide/reads, FilterResults -- all on the device."""
+    def search_top(self, seqs=None, packed=None, seq_type=abi.PROTEIN, min_k_ratio=0.05, min_k_match=10, max_results=10, flat=True):
+        """Host-buffer form that returns the reported hits only (kaamer_search_batch_top_flat; flat=False: the struct
+        form): sortMapByValue order, SetBestStartCodon for nucleotide/reads, FilterResults -- all on the device."""
         buf, offs = packed if packed is not None else pack_sequences(seqs)
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
         offs = np.ascontiguousarray(offs, dtype=np.uint64)
-        bi = abi.BatchIn(buf.ctypes.data if len(buf) else None, offs.ctypes.data, len(offs) - 1, seq_type, 0)
-        to = abi.TopnOpts(min_k_ratio, min_k_match, max_results, 0, None, None, 0, 0)
         out = C.POINTER(abi.BatchTop)()
-        abi.check(abi.lib().kaamer_search_batch_top(self._h, C.byref(bi), C.byref(to), C.byref(out)))
+        if flat:
+            abi.check(abi.lib().kaamer_search_batch_top_flat(self._h, buf.ctypes.data if len(buf) else None, offs.ctypes.data,
+                                                             len(offs) - 1, seq_type, min_k_ratio, min_k_match, max_results, C.byref(out)))
+        else:
+            bi = abi.BatchIn(buf.ctypes.data if len(buf) else None, offs.ctypes.data, len(offs) - 1, seq_type, 0)
+            to = abi.TopnOpts(min_k_ratio, min_k_match, max_results, 0, None, None, 0, 0)
+            abi.check(abi.lib().kaamer_search_batch_top(self._h, C.byref(bi), C.byref(to), C.byref(out)))
         try:
             return TopResult(out)
         finally:
             abi.lib().kaamer_batch_top_free(out)
 
-    def submit_top(self, seqs=None, packed=None, seq_type=abi.PROTEIN, min_k_ratio=0.05, min_k_match=10, max_results=10):
-        """kaamer_submit_batch_top: the batch is copied and enqueued on a free slot; -> a ticket whose wait() returns
+    def submit_top(self, seqs=None, packed=None, seq_type=abi.PROTEIN, min_k_ratio=0.05, min_k_match=10, max_results=10, flat=True):
+        """kaamer_submit_batch_top[_flat]: the batch is copied and enqueued on a free slot; -> a ticket whose wait() returns
         the TopResult.  Several tickets may be in flight; submit blocks while every slot is busy."""
         buf, offs = packed if packed is not None else pack_sequences(seqs)
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
         offs = np.ascontiguousarray(offs, dtype=np.uint64)
-        bi = abi.BatchIn(buf.ctypes.data if len(buf) else None, offs.ctypes.data, len(offs) - 1, seq_type, 0)
-        to = abi.TopnOpts(min_k_ratio, min_k_match, max_results, 0, None, None, 0, 0)
         t = C.c_void_p()
-        abi.check(abi.lib().kaamer_submit_batch_top(self._h, C.byref(bi), C.byref(to), C.byref(t)))
+        if flat:
+            abi.check(abi.lib().kaamer_submit_batch_top_flat(self._h, buf.ctypes.data if len(buf) else None, offs.ctypes.data,
+                                                             len(offs) - 1, seq_type, min_k_ratio, min_k_match, max_results, C.byref(t)))
+        else:
+            bi = abi.BatchIn(buf.ctypes.data if len(buf) else None, offs.ctypes.data, len(offs) - 1, seq_type, 0)
+            to = abi.TopnOpts(min_k_ratio, min_k_match, max_results, 0, None, None, 0, 0)
+            abi.check(abi.lib().kaamer_submit_batch_top(self._h, C.byref(bi), C.byref(to), C.byref(t)))
         return TopTicket(t)
 
     def stream(self, seq_type=abi.READS, min_k_ratio=0.05, min_k_match=10, max_results=10):
@@ -449,18 +462,38 @@ class ShardedIndex:
         abi.check(abi.lib().kaamer_index_open_sharded(arr, dev, n, C.byref(h)))
         return cls(h.value)
 
-    def search_top(self, seqs=None, packed=None, seq_type=abi.PROTEIN, min_k_ratio=0.05, min_k_match=10, max_results=10):
+    def search_top(self, seqs=None, packed=None, seq_type=abi.PROTEIN, min_k_ratio=0.05, min_k_match=10, max_results=10, flat=True):
         buf, offs = packed if packed is not None else pack_sequences(seqs)
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
         offs = np.ascontiguousarray(offs, dtype=np.uint64)
-        bi = abi.BatchIn(buf.ctypes.data if len(buf) else None, offs.ctypes.data, len(offs) - 1, seq_type, 0)
-        to = abi.TopnOpts(min_k_ratio, min_k_match, max_results, 0, None, None, 0, 0)
         out = C.POINTER(abi.BatchTop)()
-        abi.check(abi.lib().kaamer_sharded_search_batch_top(self._h, C.byref(bi), C.byref(to), C.byref(out)))
+        if flat:
+            abi.check(abi.lib().kaamer_sharded_search_batch_top_flat(self._h, buf.ctypes.data if len(buf) else None, offs.ctypes.data,
+                                                                     len(offs) - 1, seq_type, min_k_ratio, min_k_match, max_results, C.byref(out)))
+        else:
+            bi = abi.BatchIn(buf.ctypes.data if len(buf) else None, offs.ctypes.data, len(offs) - 1, seq_type, 0)
+            to = abi.TopnOpts(min_k_ratio, min_k_match, max_results, 0, None, None, 0, 0)
+            abi.check(abi.lib().kaamer_sharded_search_batch_top(self._h, C.byref(bi), C.byref(to), C.byref(out)))
         try:
             return TopResult(out)
         finally:
             abi.lib().kaamer_batch_top_free(out)
+
+    def submit_top(self, seqs=None, packed=None, seq_type=abi.PROTEIN, min_k_ratio=0.05, min_k_match=10, max_results=10):
+        """kaamer_sharded_submit_batch_top_flat -> a ticket (wait() -> TopResult); up to three calls in flight per handle"""
+        buf, offs = packed if packed is not None else pack_sequences(seqs)
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        t = C.c_void_p()
+        abi.check(abi.lib().kaamer_sharded_submit_batch_top_flat(self._h, buf.ctypes.data if len(buf) else None, offs.ctypes.data,
+                                                                 len(offs) - 1, seq_type, min_k_ratio, min_k_match, max_results, C.byref(t)))
+        return TopTicket(t, sharded=True)
+
+    def exchange_info(self):
+        """-> dict(block_bytes, need_entries, queries, adaptive) of the last finished call on the handle's first set"""
+        out = (C.c_uint64 * 4)()
+        abi.check(abi.lib().kaamer_sharded_exchange_info(self._h, out))
+        return {"block_bytes": int(out[0]), "need_entries": int(out[1]), "queries": int(out[2]), "adaptive": bool(out[3])}
 
     def close(self):
         if self._h:
@@ -475,19 +508,33 @@ class ShardedIndex:
 
 
 class TopTicket:
-    """one batch in flight (kaamer_ticket); wait() exactly once"""
+    """one batch in flight (kaamer_ticket / kaamer_sharded_ticket); wait() exactly once.  A ticket dropped unwaited is
+    discarded (kaamer_ticket_discard): its slot goes back to the pool instead of staying busy for good."""
 
-    def __init__(self, handle):
-        self._h = handle
+    def __init__(self, handle, sharded=False):
+        self._h, self._sharded = handle, sharded
 
     def wait(self):
         out = C.POINTER(abi.BatchTop)()
         h, self._h = self._h, None
-        abi.check(abi.lib().kaamer_wait_batch_top(h, C.byref(out)))
+        L = abi.lib()
+        abi.check((L.kaamer_sharded_wait_batch_top if self._sharded else L.kaamer_wait_batch_top)(h, C.byref(out)))
         try:
             return TopResult(out)
         finally:
-            abi.lib().kaamer_batch_top_free(out)
+            L.kaamer_batch_top_free(out)
+
+    def discard(self):
+        h, self._h = self._h, None
+        if h:
+            L = abi.lib()
+            (L.kaamer_sharded_ticket_discard if self._sharded else L.kaamer_ticket_discard)(h)
+
+    def __del__(self):
+        try:
+            self.discard()
+        except Exception:
+            pass
 
 
 class TopStream:
@@ -579,6 +626,13 @@ class Workspace:
 
     def exchange_pack(self, layout, d_send_ptr, stream=0):
         abi.check(abi.lib().kaamer_exchange_pack(self._h, C.byref(layout), d_send_ptr, C.c_void_p(stream)))
+
+    def exchange_stats(self, back=0):
+        """-> (merge sequence number, queries of the batch, entries the largest block any pair of ranks needed, overflow)
+        of the merge `back` calls ago on this workspace; the same figures on every rank"""
+        out = (C.c_uint64 * 4)()
+        abi.check(abi.lib().kaamer_exchange_stats(self._h, back, out))
+        return int(out[0]), int(out[1]), int(out[2]), int(out[3])
 
     def exchange_merge(self, layout, d_recv_ptr, stream=0):
         r = abi.DeviceResult()

@@ -1457,8 +1457,12 @@ struct kaamer_workspace {
     int32_t *d_top_trim, *d_top_start, *d_top_size;
     bool last_was_merge;
     // exchange step of the sharded index (kaamer_exchange_pack / _merge), allocated on first use
-    uint32_t x_world, x_qcap;
-    uint64_t x_ecap;
+    // exchange scratch: grow-only (the block layout may change from batch to batch within the buffers' capacity)
+    size_t x_dst_cap, x_src_cap, x_ent_cap, x_m_cap;
+    unsigned long long *d_x_stats;      // {queries, largest block needed, overflow, -} of the last merge's headers
+    unsigned long long *h_x_stats;      // pinned: two slots of 4 words, slot = merge sequence number & 1
+    hipEvent_t ev_x_stats[2];
+    uint64_t x_merge_seq;               // merges enqueued on this workspace
     uint32_t *d_x_dst_off, *d_x_src_off, *d_x_nq_owned, *d_x_pid, *d_x_km, *d_x_fp;
     uint64_t *d_x_ent_off;
     uint64_t *d_x_tiles;                // tile sums of the exchange's tiled scans
@@ -1524,6 +1528,19 @@ extern "C" {
 const char *kaamer_last_error(void) { return g_err; }
 int kaamer_abi_version(void) { return KAAMER_ABI_VERSION; }
 
+#ifdef KAAMER_PHASE_CLOCK
+// measurement build only: the phase clocks of count_group_kernel<., 0> since the last reset
+int kaamer_debug_phase_clock(unsigned long long out[16], int reset)
+{
+    HIPCHK(hipDeviceSynchronize());
+    static unsigned long long all[2048][16];
+    HIPCHK(hipMemcpyFromSymbol(all, HIP_SYMBOL(g_phase_clock), sizeof all));
+    for (int i = 0; i < 16; i++) { out[i] = 0; for (int b = 0; b < 2048; b++) out[i] += all[b][i]; }
+    if (reset) { memset(all, 0, sizeof all); HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_clock), all, sizeof all)); }
+    return KAAMER_OK;
+}
+#endif
+
 int kaamer_index_open_image(const kaamer_image *img, int device, kaamer_index **out)
 {
     if (!img || !out) return kaamer_fail(KAAMER_E_ARG, "index_open_image: bad argument");
@@ -1586,7 +1603,20 @@ void kaamer_index_close(kaamer_index *ix)
 {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
+    {   // calls still in flight (a ticket not yet waited for, a caller inside kaamer_search_batch) keep their slot busy:
+        // the close waits for them to be given back, then for every slot's stream
+        std::unique_lock<std::mutex> lock(ix->pool_mu);
+        for (;;) {
+            bool busy = false;
+            for (const HostSlot &h : ix->host) busy = busy || h.busy;
+            for (int i = 0; i < ix->n_top; i++) busy = busy || ix->top[i].busy;
+            if (!busy) break;
+            ix->pool_cv.wait(lock);
+        }
+    }
+    for (TopSlot &h : ix->top) if (h.stream) (void)hipStreamSynchronize(h.stream);
     for (HostSlot &h : ix->host) {
+        if (h.stream) (void)hipStreamSynchronize(h.stream);
         if (h.stream) (void)hipStreamDestroy(h.stream);
         if (h.ws) kaamer_workspace_free(h.ws);
         if (h.d_seqs) (void)hipFree(h.d_seqs);
@@ -1614,8 +1644,12 @@ void kaamer_workspace_free(kaamer_workspace *ws)
                      ws->d_pool_cursor, ws->d_lists, ws->d_list_counts, ws->d_status_out, ws->d_qinfo, ws->d_slots,
                      ws->d_slot_off, ws->d_group_first, ws->d_n_groups, ws->d_pos_words, ws->d_pos_base, ws->d_pos_off, ws->d_pos_bits, ws->d_g_keys,
                      ws->d_counter_replicas, ws->d_counters, ws->d_bsum, ws->d_chain, ws->d_tr_chain, ws->d_sched, ws->d_n_sched, ws->d_group_start, ws->d_lay_total, ws->d_slot_scale, ws->d_top_cnt, ws->d_top_pid, ws->d_top_km, ws->d_top_fp, ws->d_top_trim, ws->d_top_start, ws->d_top_size, ws->d_rep_flag, ws->d_rep_aalen, ws->d_rep_query, ws->d_rep_pid, ws->d_rep_km, ws->d_rep_fp, ws->d_rep_trim, ws->d_rep_rank, ws->d_rep_eoff, ws->d_rep_aoff, ws->d_rep_off, ws->d_rep_q, ws->d_rep_aa, ws->d_hit_off,
-                     ws->d_hit_pid, ws->d_hit_km, ws->d_hit_fp, ws->d_x_dst_off, ws->d_x_src_off, ws->d_x_nq_owned, ws->d_x_pid, ws->d_x_km, ws->d_x_fp, ws->d_x_ent_off, ws->d_x_tiles };
+                     ws->d_hit_pid, ws->d_hit_km, ws->d_hit_fp, ws->d_x_dst_off, ws->d_x_src_off, ws->d_x_nq_owned, ws->d_x_pid, ws->d_x_km, ws->d_x_fp, ws->d_x_ent_off, ws->d_x_tiles, ws->d_x_stats };
     for (void *b : bufs) if (b) (void)hipFree(b);
+    if (ws->h_x_stats) {
+        (void)hipHostFree(ws->h_x_stats);
+        for (hipEvent_t e : ws->ev_x_stats) if (e) (void)hipEventDestroy(e);
+    }
     if (ws->ev) {
         for (hipEvent_t e : *ws->ev) (void)hipEventDestroy(e);
         delete ws->ev;
@@ -2269,12 +2303,13 @@ int kaamer_exchange_pack(kaamer_workspace *ws, const kaamer_exchange_layout *L, 
     if (!ws || !L || !d_send || L->world == 0) return kaamer_fail(KAAMER_E_ARG, "exchange_pack: bad argument");
     if ((uint64_t)L->q_cap * L->world < ws->q_cap) return kaamer_fail(KAAMER_E_ARG, "exchange_pack: the layout holds fewer queries than the workspace");
     HIPCHK(hipSetDevice(ws->device));
-    if (ws->x_world != L->world || ws->x_qcap != L->q_cap || !ws->d_x_dst_off) {
+    if (ws->x_dst_cap < (size_t)L->world * L->q_cap) {
+        HIPCHK(hipStreamSynchronize((hipStream_t)stream));
         if (ws->d_x_dst_off) (void)hipFree(ws->d_x_dst_off);
-        ws->d_x_dst_off = nullptr;
+        ws->d_x_dst_off = nullptr; ws->x_dst_cap = 0;
         const int rc = dev_alloc(&ws->d_x_dst_off, (size_t)L->world * L->q_cap);
         if (rc) return rc;
-        ws->x_world = L->world; ws->x_qcap = L->q_cap;
+        ws->x_dst_cap = (size_t)L->world * L->q_cap;
     }
     XParams x;
     x_fill(x, L);
@@ -2319,19 +2354,28 @@ int kaamer_exchange_merge(kaamer_workspace *ws, const kaamer_exchange_layout *L,
     if (m_cap > ws->hit_cap) return kaamer_fail(KAAMER_E_CAPACITY, "exchange_merge: %llu entries exceed the merge workspace's max_hits (%llu)",
                                                  (unsigned long long)m_cap, (unsigned long long)ws->hit_cap);
     HIPCHK(hipSetDevice(ws->device));
-    if (ws->x_world != L->world || ws->x_qcap != L->q_cap || ws->x_ecap != L->e_cap || !ws->d_x_src_off) {
-        void *bufs[] = { ws->d_x_src_off, ws->d_x_nq_owned, ws->d_x_pid, ws->d_x_km, ws->d_x_fp, ws->d_x_ent_off };
+    if (ws->x_src_cap < (size_t)L->world * L->q_cap || ws->x_ent_cap < (size_t)L->q_cap + 1 || ws->x_m_cap < (size_t)m_cap || !ws->d_x_nq_owned) {
+        HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+        void *bufs[] = { ws->d_x_src_off, ws->d_x_nq_owned, ws->d_x_pid, ws->d_x_km, ws->d_x_fp, ws->d_x_ent_off, ws->d_x_stats };
         for (void *b : bufs) if (b) (void)hipFree(b);
         ws->d_x_src_off = ws->d_x_nq_owned = ws->d_x_pid = ws->d_x_km = ws->d_x_fp = nullptr;
-        ws->d_x_ent_off = nullptr;
+        ws->d_x_ent_off = nullptr; ws->d_x_stats = nullptr;
+        ws->x_src_cap = ws->x_ent_cap = ws->x_m_cap = 0;
         int rc = dev_alloc(&ws->d_x_src_off, (size_t)L->world * L->q_cap);
         if (!rc) rc = dev_alloc(&ws->d_x_nq_owned, 1);
         if (!rc) rc = dev_alloc(&ws->d_x_ent_off, (size_t)L->q_cap + 1);
         if (!rc) rc = dev_alloc(&ws->d_x_pid, (size_t)m_cap);
         if (!rc) rc = dev_alloc(&ws->d_x_km, (size_t)m_cap);
         if (!rc) rc = dev_alloc(&ws->d_x_fp, (size_t)m_cap);
+        if (!rc) rc = dev_alloc(&ws->d_x_stats, 4);
         if (rc) return rc;
-        ws->x_world = L->world; ws->x_qcap = L->q_cap; ws->x_ecap = L->e_cap;
+        ws->x_src_cap = (size_t)L->world * L->q_cap; ws->x_ent_cap = (size_t)L->q_cap + 1; ws->x_m_cap = (size_t)m_cap;
+    }
+    if (!ws->h_x_stats) {
+        if (hipHostMalloc((void **)&ws->h_x_stats, 8 * sizeof(unsigned long long), hipHostMallocDefault) != hipSuccess)
+            return kaamer_fail(KAAMER_E_NOMEM, "exchange_merge: pinned statistics");
+        memset(ws->h_x_stats, 0, 8 * sizeof(unsigned long long));
+        for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&ws->ev_x_stats[i], hipEventDisableTiming));
     }
     hipStream_t s = (hipStream_t)stream;
     if (!ws->clean) {  // the status word the unpack kernels may set must start from zero
@@ -2350,6 +2394,7 @@ int kaamer_exchange_merge(kaamer_workspace *ws, const kaamer_exchange_layout *L,
     x.m_pid = ws->d_x_pid; x.m_km = ws->d_x_km; x.m_fp = ws->d_x_fp;
     x.with_fp = ws->firstpos ? 1u : 0u;
     x.m_cap = m_cap;
+    x.stats = ws->d_x_stats;
     x.status = ws->d_list_counts + SLOT_STATUS;
     {
         const int rc = x_tiles(ws, L, &x);
@@ -2369,10 +2414,45 @@ int kaamer_exchange_merge(kaamer_workspace *ws, const kaamer_exchange_layout *L,
     if (wide) hipLaunchKernelGGL(x_unpack_copy_kernel<X_GROUP_WIDE>, dim3(gb), dim3(256), 0, s, x);
     else hipLaunchKernelGGL(x_unpack_copy_kernel<X_GROUP>, dim3(gb), dim3(256), 0, s, x);
     HIPCHK(hipGetLastError());
+    {   // what the W headers said, to the host: read by kaamer_exchange_stats without waiting for the merge itself
+        const int slot = (int)(ws->x_merge_seq & 1u);
+        HIPCHK(hipMemcpyAsync(ws->h_x_stats + 4 * slot, ws->d_x_stats, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipEventRecord(ws->ev_x_stats[slot], s));
+        ws->x_merge_seq++;
+    }
     return merge_device_impl(ws, ws->d_x_ent_off, ws->d_x_pid, ws->d_x_km, ws->d_x_fp, L->q_cap, ws->d_x_nq_owned, m_cap, stream, out);
 }
 
 uint32_t kaamer_workspace_query_capacity(const kaamer_workspace *ws) { return ws ? ws->q_cap : 0u; }
+
+int kaamer_exchange_layout_fit(const kaamer_exchange_layout *cap, uint32_t n_queries, uint64_t entries_per_block, kaamer_exchange_layout *out)
+{
+    if (!cap || !out || cap->world == 0) return kaamer_fail(KAAMER_E_ARG, "exchange_layout_fit: bad argument");
+    kaamer_exchange_layout L = *cap;
+    const uint64_t q = ((uint64_t)n_queries + cap->world - 1) / cap->world + 1;
+    if (q < L.q_cap) L.q_cap = (uint32_t)q;
+    uint64_t e = (entries_per_block + 3) & ~3ull;
+    if (e < 4) e = 4;
+    if (e < L.e_cap) L.e_cap = e;
+    L.block_words = (X_HDR + (uint64_t)L.q_cap + 3 * L.e_cap + 3) & ~3ull;
+    *out = L;
+    return KAAMER_OK;
+}
+
+int kaamer_exchange_stats(kaamer_workspace *ws, uint32_t back, uint64_t out[4])
+{
+    if (!ws || !out || back > 1) return kaamer_fail(KAAMER_E_ARG, "exchange_stats: bad argument (back is 0 or 1)");
+    if (ws->x_merge_seq <= back || !ws->h_x_stats) return kaamer_fail(KAAMER_E_ARG, "exchange_stats: no such merge yet");
+    const uint64_t seq = ws->x_merge_seq - 1 - back;
+    const int slot = (int)(seq & 1u);
+    HIPCHK(hipSetDevice(ws->device));
+    HIPCHK(hipEventSynchronize(ws->ev_x_stats[slot]));
+    out[0] = seq;
+    out[1] = ws->h_x_stats[4 * slot + 0];
+    out[2] = ws->h_x_stats[4 * slot + 1];
+    out[3] = ws->h_x_stats[4 * slot + 2];
+    return KAAMER_OK;
+}
 
 // grouped ncclSend / ncclRecv of equal blocks, for hosts that own an RCCL communicator and nothing else to drive it
 // (the library does not link RCCL: the symbols are looked up in the process at first use)

@@ -105,11 +105,16 @@ class ShardedSearcher:
     (every rank translates; the owner's post-steps use its own ORFs: orf_source)."""
 
     def __init__(self, index, rank, world, max_seq_bytes, max_seqs, seq_type=abi.PROTEIN, max_entries_per_peer=1 << 20,
-                 group=None, max_hits=0, g_tier_slots=0, first_pos=None, transport="torch", comm=None):
+                 group=None, max_hits=0, g_tier_slots=0, first_pos=None, transport="torch", comm=None, adaptive=True,
+                 margin=0.25):
         """first_pos: carry the lowest matching position of every hit through the exchange.  Default: as the reference
         fills PositionHits (search.go:416) -- nucleotide / reads input yes (SetBestStartCodon reads it), protein input no
         (a third less to pack, send, unpack and merge).
-        transport: "rccl" (comm: an RcclComm; made here when None), "torch", or "host" (see the module docstring)."""
+        transport: "rccl" (comm: an RcclComm; made here when None), "torch", or "host" (see the module docstring).
+        adaptive: size the blocks of a batch from what the batch before last needed (+ margin) instead of the buffers'
+        capacity, so that the all-to-all moves payload; the figures come out of the received block headers and are the
+        same on every rank (kaamer_exchange_stats).  A batch that does not fit raises KaamerError(E_CAPACITY) from
+        finish() on every rank; `run()` repeats it at full capacity."""
         assert transport in ("rccl", "torch", "host")
         self.index, self.rank, self.world, self.group = index, rank, world, group
         self.transport = transport
@@ -123,7 +128,11 @@ class ShardedSearcher:
         self.layout = abi.ExchangeLayout()
         abi.check(abi.lib().kaamer_exchange_layout_init(world, rank, self.ws.query_capacity, max_entries_per_peer,
                                                         C.byref(self.layout)))
-        L = self.layout
+        L = self.layout            # the capacity layout: what the buffers hold
+        self.wire = L              # the layout of the batch being enqueued
+        self.adaptive, self.margin = bool(adaptive), float(margin)
+        self._full_next = False    # a batch overflowed its blocks: full capacity until the statistics have caught up
+        self.n_steps = 0
         self.mws = api.Workspace(index, 64, L.q_cap, max_queries=L.q_cap, first_pos=fp, max_hits=world * L.e_cap,
                                  g_tier_slots=g_tier_slots)
         n = world * int(L.block_words)
@@ -139,26 +148,42 @@ class ShardedSearcher:
             self.h_recv = torch.empty(n, dtype=torch.int32).pin_memory()
         self.phase_ms = None
 
+    def _choose_layout(self):
+        """the block layout of the next batch: the capacity layout for the first two batches and after an overflow, then
+        what the batch before last needed + margin (that merge's header scan is long done: no stall, and every rank reads
+        the same figures, so all ranks pick the same layout without talking to each other)"""
+        if not self.adaptive or self.n_steps < 2:
+            return self.layout
+        _, nq, need, ovf = self.mws.exchange_stats(back=1)
+        if self._full_next or ovf:
+            self._full_next = False
+            return self.layout
+        fit = abi.ExchangeLayout()
+        abi.check(abi.lib().kaamer_exchange_layout_fit(C.byref(self.layout), int(nq * (1.0 + self.margin)) + 64,
+                                                       int(need * (1.0 + self.margin)) + 1024, C.byref(fit)))
+        return fit
+
     def _alltoall(self, stream):
         raw = stream.cuda_stream
+        n = self.world * int(self.wire.block_words)   # words that travel: world blocks of THIS batch's layout
         if self.transport == "rccl":  # world 1 included: the send/recv pair with oneself goes through RCCL too
             abi.check(abi.lib().kaamer_rccl_alltoall(self.comm.handle, self.send.data_ptr(), self.recv.data_ptr(),
-                                                     self.block_bytes, self.world, C.c_void_p(raw)))
+                                                     4 * int(self.wire.block_words), self.world, C.c_void_p(raw)))
             return
         if self.world == 1:
             return
         if self.transport == "torch":
             with torch.cuda.stream(stream):
-                dist.all_to_all_single(self.recv, self.send, group=self.group)
+                dist.all_to_all_single(self.recv[:n], self.send[:n], group=self.group)
             return
         with torch.cuda.stream(stream):
-            self.h_send.copy_(self.send, non_blocking=True)
+            self.h_send[:n].copy_(self.send[:n], non_blocking=True)
         stream.synchronize()
-        dist.all_to_all_single(self.h_recv, self.h_send, group=self.group)
+        dist.all_to_all_single(self.h_recv[:n], self.h_send[:n], group=self.group)
         with torch.cuda.stream(stream):
-            self.recv.copy_(self.h_recv, non_blocking=True)
+            self.recv[:n].copy_(self.h_recv[:n], non_blocking=True)
 
-    def step(self, d_seqs_ptr, d_off_ptr, n_seqs, seq_bytes, stream, topn=None, timed=False):
+    def step(self, d_seqs_ptr, d_off_ptr, n_seqs, seq_bytes, stream, topn=None, timed=False, full=False):
         """`stream`: a torch.cuda.Stream.  -> DeviceResult of the merged, owned queries (query i of the result = query
         rank + i * world of the batch).  topn: dict of kaamer_topn_device options to run the post-steps too (result in
         self.last_topn).  timed: bracket every phase with events; their ms are added to self.phase_ms after a sync."""
@@ -170,14 +195,19 @@ class ShardedSearcher:
                 e = torch.cuda.Event(enable_timing=True)
                 e.record(stream)
                 ev.append(e)
+        if not full:
+            self.wire = self._choose_layout()
+        else:
+            self.wire = self.layout
+        self.n_steps += 1
         mark()
         self.last_search = self.ws.search_device(d_seqs_ptr, d_off_ptr, n_seqs, seq_bytes, stream=raw)
         mark()
-        self.ws.exchange_pack(self.layout, self.send.data_ptr(), raw)
+        self.ws.exchange_pack(self.wire, self.send.data_ptr(), raw)
         mark()
         self._alltoall(stream)
         mark()
-        r = self.mws.exchange_merge(self.layout, self.recv.data_ptr(), raw)
+        r = self.mws.exchange_merge(self.wire, self.recv.data_ptr(), raw)
         mark()
         self.last_topn = self.topn(stream, **topn) if topn is not None else None
         mark()
@@ -209,8 +239,23 @@ class ShardedSearcher:
                 out.append(None)
                 err = err or e
         if err is not None:
+            if err.code == abi.E_CAPACITY:
+                self._full_next = True   # (every rank raises for the same batch: all fall back together)
             raise err
         return out[0], out[1]
+
+    def run(self, d_seqs_ptr, d_off_ptr, n_seqs, seq_bytes, stream, topn=None):
+        """step + finish; a batch whose blocks did not fit the adaptive layout is repeated once at full capacity
+        (on every rank: the overflow is in every header).  -> (DeviceResult, counters of the search, of the merge)"""
+        r = self.step(d_seqs_ptr, d_off_ptr, n_seqs, seq_bytes, stream, topn=topn)
+        try:
+            c = self.finish(stream)
+        except abi.KaamerError as e:
+            if e.code != abi.E_CAPACITY or self.wire is self.layout:
+                raise
+            r = self.step(d_seqs_ptr, d_off_ptr, n_seqs, seq_bytes, stream, topn=topn, full=True)
+            c = self.finish(stream)
+        return r, c[0], c[1]
 
     def close(self):
         if self._own_comm:

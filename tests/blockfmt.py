@@ -1,16 +1,18 @@
 """numpy restatement of the sharded exchange's fixed-size block format (kaamer_amd/csrc/exchange.hip.inc), test
 infrastructure only.  Rank r sends one block of `block_words` u32 words to every rank d:
 
-    [0] entries in the block   [1] status (bit 0: capacity exceeded, bit 1: first positions inside, bit 2: sender failed)
+    [0] entries in the block   [1] status (bit 0: capacity exceeded, bit 1: first positions inside, bit 2: sender failed,
+                                   bit 3: some block of this sender exceeded its capacity)
     [2] queries of the batch   [3] queries owned by d = ceil((nq - d) / W)
-    [4 .. 4+q_cap)             per owned query i (global query d + i W): number of entries
+    [4] entries the block needed   [5] the largest [4] over the sender's W blocks   [6], [7] zero
+    [8 .. 8+q_cap)             per owned query i (global query d + i W): number of entries
     then pid[e_cap], kmatch[e_cap], first_pos[e_cap]
 
 `defined_words` lists the words of a block the format defines (the device leaves the rest of a block untouched), so a
 device block and a numpy block can be compared bit for bit."""
 import numpy as np
 
-X_HDR = 4
+X_HDR = 8
 
 
 def pack_blocks(layout, nq, hit_off, hit_cnt, pid, km, fp, with_fp, src_status=0):
@@ -43,6 +45,13 @@ def pack_blocks(layout, nq, hit_off, hit_cnt, pid, km, fp, with_fp, src_status=0
         blk[1] = st | (2 if with_fp else 0) | (4 if src_status else 0)
         blk[2] = nq
         blk[3] = len(owned)
+        blk[4] = min(total, 0xFFFFFFFF)
+    need = max(int(out[d * bw + 4]) for d in range(W))
+    anyov = any(int(out[d * bw + 1]) & 1 for d in range(W))
+    for d in range(W):
+        out[d * bw + 5] = need
+        if anyov:
+            out[d * bw + 1] |= 8
     return out
 
 
@@ -72,7 +81,7 @@ def unpack_merge(layout, recv, with_fp):
     for b in blks:
         if int(b[2]) != nq or int(b[3]) != want or want > q_cap:
             raise ValueError("headers disagree")
-        if int(b[1]) & 1:
+        if int(b[1]) & 9:
             raise ValueError("block overflow")
         if int(b[1]) & 4:
             raise ValueError("peer failed")

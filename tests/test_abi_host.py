@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol(klib):
     for n in names:
         assert hasattr(klib, n), "libkaamer_hip.so lacks %s" % n
     assert sorted(abi.SYMBOLS) == names, "abi.py and include/kaamer_hip.h disagree"
-    assert klib.kaamer_abi_version() == 3
+    assert klib.kaamer_abi_version() == 4
 
 
 def test_product_does_not_use_the_oracle():

@@ -247,7 +247,7 @@ def test_sharded_through_the_c_abi(klib, oracle, gpu_device, reads, first_pos):
     d_off = torch.from_numpy(offs.view(np.int64)).cuda()
     st = torch.cuda.current_stream()
     exp = [_oracle_report(oracle, full, x, reads) for x in queries]
-    for world in (1, 2):
+    for world in (1, 2, 8):   # 8: the q mod W ownership, the block indexing and the W-way unpack at configs[3]'s width
         ranks = []
         for r in range(world):
             ix = api.Index.from_image(api.Image.from_proteins(packed=db, shard=r, n_shards=world), gpu_device)
@@ -417,7 +417,18 @@ def _gpu_worker(rank, world, port, ret, scenario):
         d_buf = torch.from_numpy(buf).cuda()
         d_off = torch.from_numpy(offs.view(np.int64)).cuda()
         st = torch.cuda.current_stream()
-        m = ss.step(d_buf.data_ptr(), d_off.data_ptr(), n_seqs, len(buf), st, topn={})
+        if scenario == "grow":
+            # three small batches size the adaptive blocks; the full batch then outgrows them on EVERY rank (the overflow is
+            # in every header), run() repeats it at full capacity, and the result is the whole batch's
+            few = api.pack_sequences(queries[:4])
+            fb, fo = torch.from_numpy(few[0]).cuda(), torch.from_numpy(few[1].view(np.int64)).cuda()
+            for _ in range(3):
+                ss.run(fb.data_ptr(), fo.data_ptr(), 4, len(few[0]), st, topn={})
+            assert int(ss.wire.e_cap) < int(ss.layout.e_cap)
+            m, cs, cm = ss.run(d_buf.data_ptr(), d_off.data_ptr(), n_seqs, len(buf), st, topn={})
+            assert ss.wire is ss.layout, "the batch should have been repeated with capacity-sized blocks"
+        else:
+            m = ss.step(d_buf.data_ptr(), d_off.data_ptr(), n_seqs, len(buf), st, topn={})
         if scenario == "fail":
             # rank 1's search ran out of its arena: BOTH ranks report it (rank 0 through the blocks it received), none hangs
             try:
@@ -427,7 +438,17 @@ def _gpu_worker(rank, world, port, ret, scenario):
                 ret[rank] = e.code
             dist.barrier()
             return
-        cs, cm = ss.finish(st)
+        if scenario != "grow":
+            cs, cm = ss.finish(st)
+            # three more batches: from the third on the blocks are sized from what the batch before last needed (the same
+            # figure on every rank, out of the received headers), so what travels is payload, not capacity
+            for _ in range(3):
+                m = ss.step(d_buf.data_ptr(), d_off.data_ptr(), n_seqs, len(buf), st, topn={})
+                cs, cm = ss.finish(st)
+            assert int(ss.wire.e_cap) < int(ss.layout.e_cap) and int(ss.wire.q_cap) <= int(ss.layout.q_cap)
+            seq_, nq_, need_, ovf_ = ss.mws.exchange_stats(0)
+            assert ovf_ == 0 and nq_ == len(queries) and need_ <= int(ss.wire.e_cap) <= int(need_ * 1.25) + 1028
+            ret["need%d" % rank] = need_
         # the blocks the device packed == the numpy restatement of the format applied to the device's own partial lists
         r = ss.last_search
         nq = cs["n_queries"] if reads else n_seqs
@@ -437,9 +458,9 @@ def _gpu_worker(rank, world, port, ret, scenario):
         h_cnt = sharded.dev_tensor(r.d_hit_cnt, nq, torch.int32).cpu().numpy()
         h_pid, h_km, h_fp = (sharded.dev_tensor(x, cap, torch.int32).cpu().numpy().view(np.uint32)
                              for x in (r.d_hit_pid, r.d_hit_kmatch, r.d_hit_first_pos))
-        want = blockfmt.pack_blocks(ss.layout, nq, h_off, h_cnt, h_pid, h_km, h_fp, True)
-        got = ss.send.cpu().numpy().view(np.uint32)
-        mask = blockfmt.defined_words(ss.layout, want, True)
+        want = blockfmt.pack_blocks(ss.wire, nq, h_off, h_cnt, h_pid, h_km, h_fp, True)
+        got = ss.send.cpu().numpy().view(np.uint32)[:len(want)]
+        mask = blockfmt.defined_words(ss.wire, want, True)
         assert np.array_equal(got[mask], want[mask]), "device blocks differ from the documented format"
         # merged + reported results of the owned queries vs the oracle on the WHOLE database
         full = O.Index.from_proteins(None, packed=db)
@@ -472,14 +493,20 @@ def _gpu_worker(rank, world, port, ret, scenario):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("scenario", ["protein", "reads"])
-def test_two_processes_one_gpu_product_path(klib, oracle, gpu_device, scenario):
-    """configs[3] in small: two ranks (two OS processes on GPU 0), each with its hash-prefix shard; the product's
-    search -> kaamer_exchange_pack -> all-to-all -> kaamer_exchange_merge -> kaamer_topn_device(orf_source) with the
-    q mod W ownership arithmetic across REAL ranks; merged hit maps, first positions and reported hits of every owned
-    query vs the oracle on the whole database; the device's blocks vs the documented format."""
-    ret = _spawn(_gpu_worker, 2, (scenario,))
-    assert len(ret) == 2 and sum(ret.values()) > 500, ret
+@pytest.mark.parametrize("scenario,world", [("protein", 2), ("reads", 2), ("protein", 6), ("reads", 6), ("grow", 2)])
+def test_ranks_on_one_gpu_product_path(klib, oracle, gpu_device, scenario, world):
+    """configs[3] in small: `world` ranks (OS processes on GPU 0; six is the most this pool lets one job put on a card),
+    each with its hash-prefix shard; the product's search -> kaamer_exchange_pack -> all-to-all -> kaamer_exchange_merge
+    -> kaamer_topn_device(orf_source) with the q mod W ownership arithmetic across REAL ranks; four batches, the later
+    ones in blocks sized from the earlier ones' need (every rank derives the same size from its received headers);
+    merged hit maps, first positions and reported hits of every owned query vs the oracle on the whole database; the
+    device's blocks vs the documented format.  "grow": a batch that outgrows its adaptive blocks is repeated at full
+    capacity by every rank."""
+    ret = _spawn(_gpu_worker, world, (scenario,))
+    needs = {v for k, v in ret.items() if str(k).startswith("need")}
+    hits = [v for k, v in ret.items() if not str(k).startswith("need")]
+    assert len(hits) == world and sum(hits) > 500, ret
+    assert len(needs) <= 1, "the ranks disagree on the block size the batch needed: %s" % ret
 
 
 @pytest.mark.gpu
@@ -561,7 +588,7 @@ def test_single_process_sharded_handle(klib, oracle, gpu_device, reads):
     ix1 = api.Index.from_image(api.Image.from_proteins(packed=db), gpu_device)
     ref = ix1.search_top(packed=q, seq_type=seq_type)
     rpid, rkm = ref.dense()
-    for world in (1, 2, 3):
+    for world in (1, 2, 3, 8):
         imgs = [api.Image.from_proteins(packed=db, shard=r, n_shards=world) for r in range(world)]
         if world == 2:   # through files: kaamer_index_open_sharded
             with tempfile.TemporaryDirectory() as td:
@@ -572,8 +599,17 @@ def test_single_process_sharded_handle(klib, oracle, gpu_device, reads):
                 sx = api.ShardedIndex.open(paths, [gpu_device] * world)
         else:
             sx = api.ShardedIndex.from_images(imgs, [gpu_device] * world)
-        for rep in range(2):   # the second call reuses every buffer
-            top = sx.search_top(packed=q, seq_type=seq_type)
+        for rep in range(3):   # the second call reuses every buffer and sizes its exchange blocks from the first call's need
+            if rep == 2:       # the two-halves form, struct entry point underneath the flat one
+                top = sx.submit_top(packed=q, seq_type=seq_type).wait()
+            else:
+                top = sx.search_top(packed=q, seq_type=seq_type, flat=(rep == 0))
+            info = sx.exchange_info()
+            assert info["adaptive"] == (rep > 0) and info["queries"] == len(queries)
+            if rep > 0:
+                words = 3 if reads else 2
+                payload = 4 * (8 + (len(queries) + world - 1) // world + words * info["need_entries"])
+                assert info["block_bytes"] <= 1.5 * payload + 8192, (world, info)
             assert top.n_queries == ref.n_queries == len(queries)
             assert top.rep_query.tolist() == ref.rep_query.tolist(), world
             assert top.top_off.tolist() == ref.top_off.tolist()

@@ -155,3 +155,67 @@ def test_concurrent_full_hit_list_callers(klib, oracle, gpu_device):
     for t in th:
         t.join()
     assert not errors, errors[:3]
+
+
+@pytest.mark.gpu
+def test_flat_entry_points_equal_the_struct_forms(klib, gpu_device):
+    """The cgo-safe forms (every caller buffer a direct argument: include/kaamer_hip.h) return what the
+    struct forms return -- kaamer_search_batch_flat, kaamer_search_batch_top_flat, kaamer_submit_batch_top_flat,
+    kaamer_stream_open_flat -- for protein and read batches."""
+    import ctypes as C
+    from kaamer_amd import abi, api, workload
+    db = workload.make_db(800, seed=14)
+    ix = api.Index.from_image(api.Image.from_proteins(packed=db), gpu_device)
+    for q, kind in ((workload.make_protein_queries(db, 90, seed=3), abi.PROTEIN), (workload.make_reads(db, 200, seed=5), abi.READS)):
+        a, b = ix.search(packed=q, seq_type=kind, flat=True), ix.search(packed=q, seq_type=kind, flat=False)
+        assert a.n_queries == b.n_queries and a.n_queries > 50
+        assert all(a.hits(i) == b.hits(i) for i in range(a.n_queries))
+        ta, tb = ix.search_top(packed=q, seq_type=kind, flat=True), ix.search_top(packed=q, seq_type=kind, flat=False)
+        tc, td = ix.submit_top(packed=q, seq_type=kind, flat=True).wait(), ix.submit_top(packed=q, seq_type=kind, flat=False).wait()
+        # the stream opened with flat options
+        h = C.c_void_p()
+        abi.check(klib.kaamer_stream_open_flat(ix._h, kind, 0.05, 10, 10, C.byref(h)))
+        buf, offs = np.ascontiguousarray(q[0]), np.ascontiguousarray(q[1])
+        abi.check(klib.kaamer_stream_push(h, buf.ctypes.data, offs.ctypes.data, len(offs) - 1))
+        out = C.POINTER(abi.BatchTop)()
+        abi.check(klib.kaamer_stream_pop(h, C.byref(out)))
+        te = api.TopResult(out)
+        klib.kaamer_batch_top_free(out)
+        klib.kaamer_stream_close(h)
+        assert ta.n_reported > 20
+        for t in (tb, tc, td, te):
+            assert t.rep_query.tolist() == ta.rep_query.tolist() and t.top_off.tolist() == ta.top_off.tolist()
+            assert t.top_pid.tolist() == ta.top_pid.tolist() and t.top_kmatch.tolist() == ta.top_kmatch.tolist()
+            assert t.trim.tolist() == ta.trim.tolist()
+
+
+@pytest.mark.gpu
+def test_discarded_tickets_give_their_slots_back(klib, gpu_device):
+    """A ticket dropped without wait() (an exception between submit and wait) must not keep its slot busy for good:
+    after more discarded tickets than there are slots a further submit still gets one, and kaamer_index_close with a
+    ticket in flight waits for it instead of destroying a stream with work queued."""
+    import threading
+    from kaamer_amd import abi, api, workload
+    db = workload.make_db(600, seed=15)
+    ix = api.Index.from_image(api.Image.from_proteins(packed=db), gpu_device)
+    q = workload.make_protein_queries(db, 70, seed=2)
+    ref = ix.search_top(packed=q)
+    for i in range(12):   # default: 4 slots
+        t = ix.submit_top(packed=q)
+        if i % 2:
+            t.discard()
+        else:
+            del t         # __del__ discards
+    done = []
+    th = threading.Thread(target=lambda: done.append(ix.submit_top(packed=q).wait()))
+    th.start()
+    th.join(60)
+    assert done and done[0].top_pid.tolist() == ref.top_pid.tolist()
+    # close while a ticket is in flight: close() waits until another thread has waited for the ticket
+    t = ix.submit_top(packed=q)
+    res = []
+    th = threading.Thread(target=lambda: (__import__("time").sleep(0.3), res.append(t.wait())))
+    th.start()
+    ix.close()
+    th.join(60)
+    assert res and res[0].top_pid.tolist() == ref.top_pid.tolist()
