@@ -598,8 +598,10 @@ typedef struct kaamer_reads kaamer_reads;
  * http.DetectContentType calls application/x-gzip, search.go:255-263, 361-366) are inflated first: every member of the
  * stream (Go's gzip.Reader is multistream); a stream that breaks off or is damaged reads as what inflated before that
  * (the reference's scanner stops at the read error and processes what it got); a first header that is no gzip header
- * is KAAMER_E_FORMAT (gzip.NewReader fails: no queries).  The same holds for kaamer_makedb_embl / _gbk
- * (inputEMBL.go:76-84, inputGBK.go:75-83); the FASTA and TSV makedb readers have no gzip branch in the reference. */
+ * gives an EMPTY read set (gzip.NewReader fails, GetQueriesFasta prints the error and returns without a query,
+ * search.go:259-263).  kaamer_makedb_embl / _gbk inflate the same way (inputEMBL.go:76-84, inputGBK.go:75-83) but report
+ * a bad first header as KAAMER_E_FORMAT (the reference log.Fatal()s there); the FASTA and TSV makedb readers have no gzip
+ * branch in the reference. */
 int kaamer_parse_fasta(const char *text, uint64_t len, kaamer_reads **out);
 int kaamer_parse_fastq(const char *text, uint64_t len, kaamer_reads **out);
 uint32_t kaamer_reads_count(const kaamer_reads *r);
@@ -614,6 +616,27 @@ const uint64_t *kaamer_reads_name_offsets(const kaamer_reads *r);  /* count + 1 
  * reference's scan) -- lines of any length are read. */
 const int32_t *kaamer_reads_plus_strand(const kaamer_reads *r);
 void kaamer_reads_free(kaamer_reads *r);
+
+/* The same readers over a FILE, in chunks (search.go:240-283: open, sniff 32 bytes, gzip.NewReader when they carry the
+ * gzip signature, bufio.Scanner line by line): a read set of any size goes through bounded memory -- BASELINE
+ * configs[4].  format: 0 = GetQueriesFasta, 1 = GetQueriesFastq.  kaamer_reader_next hands out the next records -- up
+ * to max_seqs of them, stopping once about max_bytes of sequence are in the chunk -- as a kaamer_reads (accessors above;
+ * free it with kaamer_reads_free), ready for kaamer_stream_push / kaamer_replica_stream_push; a chunk with zero records
+ * and kaamer_reader_done() = 1 is the end.  The rules that span records hold across chunks: FASTA upper-cases every
+ * record but the LAST of the file, PlusStrand is 1 on the file's first record only.  gzip: every member, a stream that
+ * breaks off or is damaged reads as what inflated before; a first header that is no gzip header: no records.
+ * strict_scanner = 1 additionally reproduces what the reference's scanner setup does to unusual input: a line of
+ * 1 048 576 bytes or more ends the input there (bufio.Scanner with a 1 MiB buffer returns false, search.go:273-274; the
+ * record being read is emitted as the last one), and a file whose first 32 bytes are not what http.DetectContentType
+ * calls "text/plain; charset=utf-8" (a UTF-16 byte-order mark, a control byte) yields no records (search.go:266-270).
+ * strict_scanner = 0 reads lines of any length. */
+typedef struct kaamer_reader kaamer_reader;
+int kaamer_reader_open(const char *path, int format, int strict_scanner, kaamer_reader **out);
+int kaamer_reader_open_fd(int fd, int format, int strict_scanner, kaamer_reader **out); /* fd stays the caller's */
+int kaamer_reader_next(kaamer_reader *rd, uint32_t max_seqs, uint64_t max_bytes, kaamer_reads **out);
+int kaamer_reader_done(const kaamer_reader *rd);
+uint64_t kaamer_reader_records(const kaamer_reader *rd);   /* records handed out so far */
+void kaamer_reader_close(kaamer_reader *rd);
 
 #ifdef __cplusplus
 }

@@ -214,6 +214,12 @@ SYMBOLS = {
     "kaamer_reads_name_offsets": (C.POINTER(C.c_uint64), [C.c_void_p]),
     "kaamer_reads_plus_strand": (C.POINTER(C.c_int32), [C.c_void_p]),
     "kaamer_reads_free": (None, [C.c_void_p]),
+    "kaamer_reader_open": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "kaamer_reader_open_fd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "kaamer_reader_next": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "kaamer_reader_done": (C.c_int, [C.c_void_p]),
+    "kaamer_reader_records": (C.c_uint64, [C.c_void_p]),
+    "kaamer_reader_close": (None, [C.c_void_p]),
 }
 
 _lib = None

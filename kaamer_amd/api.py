@@ -669,6 +669,82 @@ class Workspace:
             pass
 
 
+def _reads_to_arrays(h):
+    """a kaamer_reads handle -> (seqs u8, offsets u64, size_in_kmer, names bytes, name offsets, plus_strand), copied"""
+    L = abi.lib()
+    n = L.kaamer_reads_count(h)
+    offs = np.ctypeslib.as_array(L.kaamer_reads_offsets(h), shape=(n + 1,)).copy()
+    noff = np.ctypeslib.as_array(L.kaamer_reads_name_offsets(h), shape=(n + 1,)).copy()
+    seqs = np.ctypeslib.as_array(L.kaamer_reads_seqs(h), shape=(int(offs[n]),)).copy() if offs[n] else np.zeros(0, np.uint8)
+    names = bytes(np.ctypeslib.as_array(C.cast(L.kaamer_reads_names(h), C.POINTER(C.c_uint8)), shape=(int(noff[n]),))) if noff[n] else b""
+    size = np.ctypeslib.as_array(L.kaamer_reads_size_in_kmer(h), shape=(n,)).copy() if n else np.zeros(0, np.int32)
+    plus = np.ctypeslib.as_array(L.kaamer_reads_plus_strand(h), shape=(n,)).copy() if n else np.zeros(0, np.int32)
+    return seqs, offs, size, names, noff, plus
+
+
+class Reader:
+    """kaamer_reader_*: GetQueriesFasta / GetQueriesFastq over a file in chunks (gzip inflated incrementally)"""
+
+    def __init__(self, path=None, fmt="fastq", strict=False, fd=None):
+        h = C.c_void_p()
+        f = 1 if fmt == "fastq" else 0
+        if fd is not None:
+            abi.check(abi.lib().kaamer_reader_open_fd(fd, f, int(strict), C.byref(h)))
+        else:
+            abi.check(abi.lib().kaamer_reader_open(str(path).encode(), f, int(strict), C.byref(h)))
+        self._h = h
+
+    def next_handle(self, max_seqs, max_bytes):
+        """-> a raw kaamer_reads handle (free with kaamer_reads_free), or None at the end"""
+        r = C.c_void_p()
+        abi.check(abi.lib().kaamer_reader_next(self._h, max_seqs, max_bytes, C.byref(r)))
+        if abi.lib().kaamer_reads_count(r) == 0 and self.done:
+            abi.lib().kaamer_reads_free(r)
+            return None
+        return r
+
+    def next(self, max_seqs=1 << 20, max_bytes=1 << 28):
+        """-> (seqs, offsets, size_in_kmer, names, name_offsets, plus_strand) of the next chunk, or None at the end"""
+        r = self.next_handle(max_seqs, max_bytes)
+        if r is None:
+            return None
+        try:
+            return _reads_to_arrays(r)
+        finally:
+            abi.lib().kaamer_reads_free(r)
+
+    @property
+    def done(self):
+        return bool(abi.lib().kaamer_reader_done(self._h))
+
+    @property
+    def records(self):
+        return int(abi.lib().kaamer_reader_records(self._h))
+
+    def records_list(self, max_seqs=1 << 20, max_bytes=1 << 28):
+        """every record of the file as parse_reads returns them (tests)"""
+        out = []
+        while True:
+            c = self.next(max_seqs, max_bytes)
+            if c is None:
+                return out
+            seqs, offs, size, names, noff, plus = c
+            sb = bytes(seqs)
+            out += [dict(seq=sb[int(offs[i]):int(offs[i + 1])].decode("latin-1"), name=names[int(noff[i]):int(noff[i + 1])].decode("latin-1"),
+                         size=int(size[i]), plus=bool(plus[i])) for i in range(len(size))]
+
+    def close(self):
+        if self._h:
+            abi.lib().kaamer_reader_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def parse_reads(text, fmt="fasta"):
     """GetQueriesFasta / GetQueriesFastq on a text buffer -> list of dict(seq, name, size, plus)"""
     data = text.encode("latin-1") if isinstance(text, str) else bytes(text)

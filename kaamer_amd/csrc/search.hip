@@ -2301,7 +2301,8 @@ static void x_fill(XParams &x, const kaamer_exchange_layout *L)
 int kaamer_exchange_pack(kaamer_workspace *ws, const kaamer_exchange_layout *L, uint32_t *d_send, void *stream)
 {
     if (!ws || !L || !d_send || L->world == 0) return kaamer_fail(KAAMER_E_ARG, "exchange_pack: bad argument");
-    if ((uint64_t)L->q_cap * L->world < ws->q_cap) return kaamer_fail(KAAMER_E_ARG, "exchange_pack: the layout holds fewer queries than the workspace");
+    // (a layout fitted to fewer queries than the batch turns out to have is an overflow like any other: flagged in the
+    // block headers by the scan, reported by every owner)
     HIPCHK(hipSetDevice(ws->device));
     if (ws->x_dst_cap < (size_t)L->world * L->q_cap) {
         HIPCHK(hipStreamSynchronize((hipStream_t)stream));

@@ -57,9 +57,13 @@ def test_a_stream_that_breaks_off_reads_as_its_prefix(klib):
     _same_reads(api.parse_reads(bytes(bad), "fasta"), api.parse_reads(prefix, "fasta"))
 
 
-def test_not_gzip_after_all_is_an_error(klib):
+def test_not_gzip_after_all_reads_as_no_queries(klib):
+    """the signature, then no valid header: gzip.NewReader fails, GetQueriesFasta prints the error and returns without a
+    query (search.go:259-263) -- an empty read set, not an error; the makedb readers log.Fatal there: KAAMER_E_FORMAT"""
+    bad = b"\x1f\x8b\x08" + b"\xff" * 40
+    assert api.parse_reads(bad, "fasta") == [] and api.parse_reads(bad, "fastq") == []
     with pytest.raises(abi.KaamerError) as e:
-        api.parse_reads(b"\x1f\x8b\x08" + b"\xff" * 40, "fasta")     # the signature, then no valid header
+        api.Proteins.from_embl(bad)
     assert e.value.code == abi.E_FORMAT
 
 
