@@ -53,6 +53,8 @@ enum { KAAMER_NUCLEOTIDE = 0, KAAMER_PROTEIN = 1, KAAMER_READS = 2 };
 const char *kaamer_last_error(void);
 int kaamer_abi_version(void);
 
+typedef struct kaamer_reads kaamer_reads;   /* parsed query records: "Readers" at the end of this file */
+
 /* ------------------------------------------------------------------------- */
 /* K-mer codec (host) — replaces K_.EncodeKmer / CreateBytesKey,              */
 /* pkg/kvstore/k_store.go:66-76,91-117.                                       */
@@ -547,6 +549,41 @@ int kaamer_sharded_submit_batch_top_flat(kaamer_sharded_index *sx, const uint8_t
  * call's need (payload) rather than the buffers' capacity }. */
 int kaamer_sharded_exchange_info(kaamer_sharded_index *sx, uint64_t out[4]);
 
+/* ------------------------------------------------------------------------- */
+/* One process, the same database on several devices (SURVEY 8e "replicas only": */
+/* a database that fits one device is not sharded, the query stream is split;     */
+/* BASELINE configs[4]).  The reference is ONE server process (api/server.go:47-65) */
+/* whose FastqSearch takes a file (search_fastq.go:60-136).                        */
+/* ------------------------------------------------------------------------- */
+typedef struct kaamer_replicas kaamer_replicas;
+/* the image is read once and made resident on every devices[i] */
+int kaamer_index_open_replicas(const char *path, const int *devices, uint32_t n, kaamer_replicas **out);
+int kaamer_index_open_replicas_image(const kaamer_image *img, const int *devices, uint32_t n, kaamer_replicas **out);
+uint32_t kaamer_replicas_count(const kaamer_replicas *r);
+kaamer_index *kaamer_replicas_index(const kaamer_replicas *r, uint32_t i);   /* replica i: every single-index call works on it */
+void kaamer_replicas_close(kaamer_replicas *r);
+/* A FIFO of chunks over the set: chunk k goes to replica k mod n (its own slots, stream and staging), pop returns the
+ * chunks in push order.  push returns KAAMER_E_BUSY when every slot of the replica whose turn it is holds one of this
+ * stream's chunks: pop first.  One thread per stream. */
+typedef struct kaamer_replica_stream kaamer_replica_stream;
+int kaamer_replica_stream_open_flat(kaamer_replicas *r, int32_t seq_type, double min_k_ratio, int64_t min_k_match,
+                                    uint32_t max_results, kaamer_replica_stream **out);
+int kaamer_replica_stream_push(kaamer_replica_stream *rs, const uint8_t *seqs, const uint64_t *offsets, uint32_t n_seqs);
+int kaamer_replica_stream_pop(kaamer_replica_stream *rs, kaamer_batch_top **out);
+uint32_t kaamer_replica_stream_pending(const kaamer_replica_stream *rs);
+void kaamer_replica_stream_close(kaamer_replica_stream *rs);
+/* FastqSearch / ProteinSearch over a FILE of any size (search_fastq.go:60-136, search_protein.go:40-118: reader ->
+ * queryChan -> workers -> result handler): kaamer_reader_* (incremental, gzip; strict_scanner as there) feeds chunks of
+ * at most chunk_seqs records / about chunk_bytes of sequence round-robin to the replicas, up to in_flight chunks per
+ * replica in flight (0: three); `cb` is called once per chunk, in input order, with the chunk's records and its
+ * reported hits (both valid during the call only); first_seq = index of the chunk's first record in the file;
+ * rep_query / q[].src_seq of `top` count from the chunk's first record.  A non-zero return of cb stops the run.
+ * `total` (may be NULL) receives the summed work counters.  Memory: in_flight x replicas chunks, whatever the file size. */
+typedef int (*kaamer_chunk_cb)(void *user, uint64_t first_seq, const kaamer_reads *chunk, const kaamer_batch_top *top);
+int kaamer_search_file(kaamer_replicas *r, const char *path, int format, int strict_scanner, int32_t seq_type,
+                       double min_k_ratio, int64_t min_k_match, uint32_t max_results, uint32_t chunk_seqs,
+                       uint64_t chunk_bytes, uint32_t in_flight, kaamer_chunk_cb cb, void *user, kaamer_counters *total);
+
 /* Waits for `stream`, copies the counters to the host and reports a deferred
  * KAAMER_E_CAPACITY if a device-side bound was exceeded during the batch. */
 int kaamer_workspace_finish(kaamer_workspace *ws, void *stream, kaamer_counters *out);
@@ -593,7 +630,6 @@ int32_t kaamer_set_best_start_codon(const uint32_t *kmatch_sorted, const uint32_
 /* the reference's quirks (every FASTA record but the last is upper-cased; '*' */
 /* rule; FASTQ sequence lines must match ^[ATGCNatgcn]+$).                     */
 /* ------------------------------------------------------------------------- */
-typedef struct kaamer_reads kaamer_reads;
 /* `text` is the bytes of the file.  Bytes that start with the gzip signature (what the reference's
  * http.DetectContentType calls application/x-gzip, search.go:255-263, 361-366) are inflated first: every member of the
  * stream (Go's gzip.Reader is multistream); a stream that breaks off or is damaged reads as what inflated before that

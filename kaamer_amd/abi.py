@@ -214,6 +214,18 @@ SYMBOLS = {
     "kaamer_reads_name_offsets": (C.POINTER(C.c_uint64), [C.c_void_p]),
     "kaamer_reads_plus_strand": (C.POINTER(C.c_int32), [C.c_void_p]),
     "kaamer_reads_free": (None, [C.c_void_p]),
+    "kaamer_index_open_replicas": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.c_uint32, C.POINTER(C.c_void_p)]),
+    "kaamer_index_open_replicas_image": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.c_uint32, C.POINTER(C.c_void_p)]),
+    "kaamer_replicas_count": (C.c_uint32, [C.c_void_p]),
+    "kaamer_replicas_index": (C.c_void_p, [C.c_void_p, C.c_uint32]),
+    "kaamer_replicas_close": (None, [C.c_void_p]),
+    "kaamer_replica_stream_open_flat": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.c_int64, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "kaamer_replica_stream_push": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
+    "kaamer_replica_stream_pop": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "kaamer_replica_stream_pending": (C.c_uint32, [C.c_void_p]),
+    "kaamer_replica_stream_close": (None, [C.c_void_p]),
+    "kaamer_search_file": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int32, C.c_double, C.c_int64, C.c_uint32, C.c_uint32,
+                                     C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(Counters)]),
     "kaamer_reader_open": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "kaamer_reader_open_fd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "kaamer_reader_next": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(C.c_void_p)]),

@@ -507,6 +507,67 @@ class ShardedIndex:
             pass
 
 
+class Replicas:
+    """kaamer_index_open_replicas*: the same database resident on several devices of ONE process; chunks of a read set are
+    dealt round-robin (kaamer_replica_stream_*), or a whole file is searched (kaamer_search_file)."""
+
+    CHUNK_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(abi.BatchTop))
+
+    def __init__(self, handle):
+        self._h = C.c_void_p(handle)
+
+    @classmethod
+    def from_image(cls, image, devices):
+        dev = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        abi.check(abi.lib().kaamer_index_open_replicas_image(image._h, dev, len(devices), C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def open(cls, path, devices):
+        dev = (C.c_int * len(devices))(*devices)
+        h = C.c_void_p()
+        abi.check(abi.lib().kaamer_index_open_replicas(str(path).encode(), dev, len(devices), C.byref(h)))
+        return cls(h.value)
+
+    def __len__(self):
+        return int(abi.lib().kaamer_replicas_count(self._h))
+
+    def search_file(self, path, fmt="fastq", seq_type=abi.READS, min_k_ratio=0.05, min_k_match=10, max_results=10,
+                    chunk_seqs=1 << 20, chunk_bytes=1 << 28, in_flight=0, strict=False, on_chunk=None):
+        """kaamer_search_file.  on_chunk(first_seq, reads_handle, TopResult) per chunk, in input order (the reads handle is
+        valid during the call: kaamer_reads_* accessors / api._reads_to_arrays).  -> summed counters"""
+        err = []
+
+        def cb(user, first, reads, top):
+            try:
+                if on_chunk is not None:
+                    on_chunk(int(first), C.c_void_p(reads), TopResult(top))
+                return 0
+            except BaseException as e:  # noqa: BLE001  (must not propagate through the C frames)
+                err.append(e)
+                return 1
+        c = abi.Counters()
+        fn = self.CHUNK_CB(cb)
+        rc = abi.lib().kaamer_search_file(self._h, str(path).encode(), 1 if fmt == "fastq" else 0, int(strict), seq_type, min_k_ratio,
+                                          min_k_match, max_results, chunk_seqs, chunk_bytes, in_flight, C.cast(fn, C.c_void_p), None, C.byref(c))
+        if err:
+            raise err[0]
+        abi.check(rc)
+        return c.as_dict()
+
+    def close(self):
+        if self._h:
+            abi.lib().kaamer_replicas_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class TopTicket:
     """one batch in flight (kaamer_ticket / kaamer_sharded_ticket); wait() exactly once.  A ticket dropped unwaited is
     discarded (kaamer_ticket_discard): its slot goes back to the pool instead of staying busy for good."""

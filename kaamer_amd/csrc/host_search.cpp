@@ -70,9 +70,13 @@ struct RecordParser {
         if (star_rule && !seq.empty() && seq.back() == '*') size--;         // search.go:291-293,315-317
         const size_t at = r->seqs.size();
         r->seqs.resize(at + seq.size());
-        for (size_t i = 0; i < seq.size(); i++) {
-            const char c = seq[i];
-            r->seqs[at + i] = (uint8_t)((upper && c >= 'a' && c <= 'z') ? c - 32 : c);  // strings.ToUpper (:295)
+        if (!upper) {
+            memcpy(r->seqs.data() + at, seq.data(), seq.size());
+        } else {
+            for (size_t i = 0; i < seq.size(); i++) {
+                const char c = seq[i];
+                r->seqs[at + i] = (uint8_t)((c >= 'a' && c <= 'z') ? c - 32 : c);  // strings.ToUpper (:295)
+            }
         }
         r->offsets.push_back(r->seqs.size());
         r->size_in_kmer.push_back(size);
@@ -100,9 +104,12 @@ struct RecordParser {
             if (!seq.empty()) { push(r, false, false); seq.clear(); name.clear(); }
             name.assign(b + 1, e);
         } else {
+            static const struct NtTable {   // ^[ATGCNatgcn]+$ (search.go:340,386)
+                bool ok[256];
+                NtTable() { memset(ok, 0, sizeof ok); for (const char *c = "ATGCNatgcn"; *c; c++) ok[(uint8_t)*c] = true; }
+            } nt;
             bool is_seq = true;
-            for (const char *c = b; c < e && is_seq; c++)
-                is_seq = *c == 'A' || *c == 'T' || *c == 'G' || *c == 'C' || *c == 'N' || *c == 'a' || *c == 't' || *c == 'g' || *c == 'c' || *c == 'n';
+            for (const char *c = b; c < e && is_seq; c++) is_seq = nt.ok[(uint8_t)*c];
             if (is_seq) seq.assign(b, e);
         }
     }

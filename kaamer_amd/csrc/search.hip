@@ -2864,6 +2864,7 @@ int kaamer_search_batch(kaamer_index *ix, const kaamer_batch_in *in, kaamer_batc
 
 #include "host_top.hip.inc"
 #include "host_sharded.hip.inc"
+#include "host_replicas.hip.inc"
 
 void kaamer_batch_free(kaamer_batch_out *out)
 {

@@ -272,3 +272,22 @@ def make_db_zipf(n_proteins, seed=SEED + 7, n_motifs=300000, zipf_a=0.7, per_res
 def unpack(packed):
     buf, offs = packed
     return [bytes(buf[int(offs[i]):int(offs[i + 1])]) for i in range(len(offs) - 1)]
+
+
+def fastq_text(reads):
+    """packed reads -> FASTQ text (numpy, no per-read Python): "@r\\n<seq>\\n+\\n<quality 'I' x len>\\n" per read."""
+    buf, offs = reads
+    offs = offs.astype(np.int64)
+    lens = offs[1:] - offs[:-1]
+    rec = 2 * lens + 7
+    start = np.zeros(len(lens) + 1, dtype=np.int64)
+    np.cumsum(rec, out=start[1:])
+    out = np.full(int(start[-1]), ord("I"), dtype=np.uint8)
+    s0 = start[:-1]
+    out[s0] = ord("@"); out[s0 + 1] = ord("r"); out[s0 + 2] = 10
+    dst = np.repeat(s0 + 3 - offs[:-1], lens) + np.arange(int(offs[-1]), dtype=np.int64)
+    out[dst] = buf[:int(offs[-1])]
+    e = s0 + 3 + lens
+    out[e] = 10; out[e + 1] = ord("+"); out[e + 2] = 10
+    out[start[1:] - 1] = 10
+    return out.tobytes()
