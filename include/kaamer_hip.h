@@ -467,7 +467,8 @@ void kaamer_stream_close(kaamer_stream *st);
 typedef struct {
     uint32_t world, rank;
     uint32_t q_cap;        /* owned queries a block can describe                 */
-    uint32_t reserved;
+    uint32_t arrays;       /* entry arrays in a block: 3 = id, Kmatch, first     */
+                           /* position; 2 = no first positions (0 reads as 3)    */
     uint64_t e_cap;        /* partial (id, Kmatch, first position) entries/block */
     uint64_t block_words;  /* u32 words per block; send / receive buffers hold   */
                            /* world blocks                                       */
@@ -478,13 +479,14 @@ typedef struct {
 int kaamer_exchange_layout_init(uint32_t world, uint32_t rank, uint32_t max_queries,
                                 uint64_t max_entries_per_peer, kaamer_exchange_layout *out);
 /* The layout of ONE batch inside the same buffers: blocks for n_queries queries of the batch and entries_per_block
- * partial entries (both cut to the capacity layout).  What the all-to-all moves is world blocks of THIS layout's
+ * partial entries (both cut to the capacity layout), without room for first positions when the workspaces do not
+ * compute them (with_first_pos = 0: first_pos = 2 on both workspaces).  What the all-to-all moves is world blocks of THIS layout's
  * block_words, contiguous from the start of the buffers -- payload, not capacity.  Every rank must use the same layout
  * for a batch: derive the two figures from kaamer_exchange_stats of an earlier batch (identical on all ranks) plus a
  * margin; a batch that does not fit fails on every rank with KAAMER_E_CAPACITY and is repeated with the capacity
  * layout. */
 int kaamer_exchange_layout_fit(const kaamer_exchange_layout *capacity, uint32_t n_queries, uint64_t entries_per_block,
-                               kaamer_exchange_layout *out);
+                               int32_t with_first_pos, kaamer_exchange_layout *out);
 /* What the W block headers of an earlier kaamer_exchange_merge on `merge_ws` said, the same on every rank:
  * out = { merge sequence number, queries of the batch, entries the largest block between ANY pair of ranks needed,
  * non-zero if a block overflowed }.  back = 0: the last merge enqueued, 1: the one before.  Waits for that merge's

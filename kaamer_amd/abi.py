@@ -84,7 +84,7 @@ class TopnOpts(C.Structure):
 
 
 class ExchangeLayout(C.Structure):
-    _fields_ = [("world", C.c_uint32), ("rank", C.c_uint32), ("q_cap", C.c_uint32), ("reserved", C.c_uint32),
+    _fields_ = [("world", C.c_uint32), ("rank", C.c_uint32), ("q_cap", C.c_uint32), ("arrays", C.c_uint32),
                 ("e_cap", C.c_uint64), ("block_words", C.c_uint64)]
 
 
@@ -158,7 +158,7 @@ SYMBOLS = {
                                       C.c_void_p, C.POINTER(DeviceResult)]),
     "kaamer_exchange_layout_init": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, C.POINTER(ExchangeLayout)]),
     "kaamer_workspace_query_capacity": (C.c_uint32, [C.c_void_p]),
-    "kaamer_exchange_layout_fit": (C.c_int, [C.POINTER(ExchangeLayout), C.c_uint32, C.c_uint64, C.POINTER(ExchangeLayout)]),
+    "kaamer_exchange_layout_fit": (C.c_int, [C.POINTER(ExchangeLayout), C.c_uint32, C.c_uint64, C.c_int32, C.POINTER(ExchangeLayout)]),
     "kaamer_exchange_stats": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64)]),
     "kaamer_exchange_pack": (C.c_int, [C.c_void_p, C.POINTER(ExchangeLayout), C.c_void_p, C.c_void_p]),
     "kaamer_exchange_merge": (C.c_int, [C.c_void_p, C.POINTER(ExchangeLayout), C.c_void_p, C.c_void_p, C.POINTER(DeviceResult)]),

@@ -2270,6 +2270,7 @@ int kaamer_exchange_layout_init(uint32_t world, uint32_t rank, uint32_t max_quer
     out->world = world;
     out->rank = rank;
     out->q_cap = (max_queries + world - 1) / world + 1;
+    out->arrays = 3;
     out->e_cap = (max_entries_per_peer + 3) & ~3ull;
     out->block_words = (X_HDR + (uint64_t)out->q_cap + 3 * out->e_cap + 3) & ~3ull;
     return KAAMER_OK;
@@ -2301,6 +2302,7 @@ static void x_fill(XParams &x, const kaamer_exchange_layout *L)
 int kaamer_exchange_pack(kaamer_workspace *ws, const kaamer_exchange_layout *L, uint32_t *d_send, void *stream)
 {
     if (!ws || !L || !d_send || L->world == 0) return kaamer_fail(KAAMER_E_ARG, "exchange_pack: bad argument");
+    if (L->arrays == 2 && ws->firstpos) return kaamer_fail(KAAMER_E_ARG, "exchange_pack: the layout has no room for the first positions this workspace computes");
     // (a layout fitted to fewer queries than the batch turns out to have is an overflow like any other: flagged in the
     // block headers by the scan, reported by every owner)
     HIPCHK(hipSetDevice(ws->device));
@@ -2350,6 +2352,7 @@ int kaamer_exchange_merge(kaamer_workspace *ws, const kaamer_exchange_layout *L,
                           kaamer_device_result *out)
 {
     if (!ws || !L || !d_recv || !out || L->world == 0) return kaamer_fail(KAAMER_E_ARG, "exchange_merge: bad argument");
+    if (L->arrays == 2 && ws->firstpos) return kaamer_fail(KAAMER_E_ARG, "exchange_merge: the layout has no room for the first positions this workspace wants");
     if (L->q_cap > ws->q_cap) return kaamer_fail(KAAMER_E_CAPACITY, "exchange_merge: %u owned queries exceed the merge workspace (%u)", L->q_cap, ws->q_cap);
     const uint64_t m_cap = (uint64_t)L->world * L->e_cap;
     if (m_cap > ws->hit_cap) return kaamer_fail(KAAMER_E_CAPACITY, "exchange_merge: %llu entries exceed the merge workspace's max_hits (%llu)",
@@ -2426,16 +2429,19 @@ int kaamer_exchange_merge(kaamer_workspace *ws, const kaamer_exchange_layout *L,
 
 uint32_t kaamer_workspace_query_capacity(const kaamer_workspace *ws) { return ws ? ws->q_cap : 0u; }
 
-int kaamer_exchange_layout_fit(const kaamer_exchange_layout *cap, uint32_t n_queries, uint64_t entries_per_block, kaamer_exchange_layout *out)
+int kaamer_exchange_layout_fit(const kaamer_exchange_layout *cap, uint32_t n_queries, uint64_t entries_per_block, int32_t with_first_pos,
+                               kaamer_exchange_layout *out)
 {
     if (!cap || !out || cap->world == 0) return kaamer_fail(KAAMER_E_ARG, "exchange_layout_fit: bad argument");
     kaamer_exchange_layout L = *cap;
+    L.arrays = with_first_pos ? 3u : 2u;   // a protein search without -pos sends no first positions: no room for them either
     const uint64_t q = ((uint64_t)n_queries + cap->world - 1) / cap->world + 1;
     if (q < L.q_cap) L.q_cap = (uint32_t)q;
     uint64_t e = (entries_per_block + 3) & ~3ull;
     if (e < 4) e = 4;
     if (e < L.e_cap) L.e_cap = e;
-    L.block_words = (X_HDR + (uint64_t)L.q_cap + 3 * L.e_cap + 3) & ~3ull;
+    L.block_words = (X_HDR + (uint64_t)L.q_cap + (uint64_t)L.arrays * L.e_cap + 3) & ~3ull;
+    if (L.block_words > cap->block_words) L = *cap;   // never beyond what the buffers hold
     *out = L;
     return KAAMER_OK;
 }

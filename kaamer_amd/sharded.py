@@ -160,7 +160,7 @@ class ShardedSearcher:
             return self.layout
         fit = abi.ExchangeLayout()
         abi.check(abi.lib().kaamer_exchange_layout_fit(C.byref(self.layout), int(nq * (1.0 + self.margin)) + 64,
-                                                       int(need * (1.0 + self.margin)) + 1024, C.byref(fit)))
+                                                       int(need * (1.0 + self.margin)) + 1024, int(self.ws_first_pos), C.byref(fit)))
         return fit
 
     def _alltoall(self, stream):
