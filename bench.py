@@ -149,12 +149,16 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--db-proteins", type=int, default=560000)
-    ap.add_argument("--db", choices=["sp", "zipf", "zipf-mid", "ur-lite"], default="sp",
+    ap.add_argument("--db", choices=["sp", "zipf", "zipf-mid", "ur-lite"], default=None,
                     help="sp = DB-SP of SURVEY 8d (default); zipf = the same size with Zipf-distributed shared motifs "
                          "(postings lists of 1e4 and more), zipf-mid = a middle skew (longest list ~1e3): reported secondary "
                          "lines, never the headline; ur-lite = the DB-SP generator scaled to --ur-residues (default 5e9: "
-                         "a database that is actually sharded; use with --mode sharded, every rank builds only its shard)")
-    ap.add_argument("--ur-residues", type=float, default=5e9)
+                         "a database that is actually sharded; every rank builds only its shard).  Default: sp; with --mode sharded "
+                         "ur-lite at 1e9 residues per GPU (13 x DB-SP per 8 GPUs: every device holds 1/N of a table that grows with N)")
+    ap.add_argument("--ur-residues", type=float, default=0.0, help="residues of --db ur-lite (default: 1e9 per GPU in sharded mode, else 5e9)")
+    ap.add_argument("--exchange-at-w1", type=int, default=0,
+                    help="sharded mode at N = 1: 1 = run pack / all-to-all / merge although the one shard's lists are the results "
+                         "(profiling the exchange code on one GPU); 0 (default) = the post-steps run on the search results")
     ap.add_argument("--workload", choices=["protein", "reads", "mix"], default="protein",
                     help="protein = BASELINE configs[1] (default); reads = configs[2]: 150-nt reads, 6-frame path; "
                          "mix = Q-mix of configs[4]: 100/150/250-nt reads + 5 %% long reads")
@@ -213,6 +217,10 @@ def main():
     def emit(line):
         os.write(json_fd, (line + "\n").encode())
 
+    if args.db is None:
+        args.db = "ur-lite" if args.mode == "sharded" else "sp"
+    if args.ur_residues <= 0:
+        args.ur_residues = 1e9 * max(1, args.gpus) if args.mode == "sharded" else 5e9
     nucl = args.workload in ("reads", "mix")
     if args.queries <= 0:
         args.queries = 1000000 if nucl else 10000
@@ -297,7 +305,7 @@ def main():
         # scales them from the previous batch's hits per k-mer, up to what the hit arrays were provisioned for)
         args.max_hits = int(2.0 * int(args.queries * (125 if nucl else 365) * (0.065 + 2.18 * float(int(db[1][-1])) / 1e9) * 1.3))
     ws_kw = dict(seq_type=seq_type, max_hits=args.max_hits or ((64 << 20) if nucl else 0), g_tier_slots=args.g_tier_slots,
-                 compact=bool(args.compact))
+                 compact=bool(args.compact), concurrent_batches=args.inflight)
     stream = torch.cuda.current_stream().cuda_stream
 
     def exchange_entries():
@@ -332,6 +340,11 @@ def main():
         if final_batch is not None:   # leave the results of this batch in the workspaces (the parity check reads them)
             final = searcher.step(bufs[final_batch].data_ptr(), offs[final_batch].data_ptr(), args.queries, sizes[final_batch], tstream)
             searcher.finish(tstream)
+        if searcher.direct:   # one shard: its lists are the results, nothing is packed or exchanged
+            return {"transport": "none (one shard: the partial lists are the results; --exchange-at-w1 1 runs the exchange anyway)",
+                    "rccl_comm_ranks": searcher.comm.world if searcher.comm is not None else None,
+                    "phase_ms_per_batch": {k: ph[k] / ph["batches"] for k in sharded.PHASES}, "phase_batches": ph["batches"],
+                    "wire_bytes_per_rank_per_batch": 0, "payload_bytes_per_rank_per_batch": 0}, final
         L = searcher.wire   # the layout of the last batch: blocks sized from what an earlier batch needed, not the capacity
         bw, W = int(L.block_words), int(L.world)
         hdr = torch.stack([searcher.send[d * bw:d * bw + 8] for d in range(W)]).cpu().numpy()   # [entries, status, nq, owned, need, max need, -, -]
@@ -354,7 +367,7 @@ def main():
         tstream = torch.cuda.current_stream()
         searcher = sharded.ShardedSearcher(ix, rank, world, max_bytes, args.queries, seq_type=seq_type,
                                            max_entries_per_peer=exchange_entries(), max_hits=shard_hits(),
-                                           transport=args.transport)
+                                           transport=args.transport, direct_at_world1=not args.exchange_at_w1)
 
         def launch(i):
             b = i % n_distinct
@@ -440,15 +453,22 @@ def main():
     # gives every kernel alone on the device (reported next to the timed-region figures)
     tm_alone = None
     if args.inflight > 1 and not sharded_mode:
-        wss[0].set_timing(1)
-        wss[0].reset_timers()
+        # (a workspace of its own: the timed region's workspaces were created for batches in flight next to each other --
+        # concurrent_batches -- and launch the counting kernel accordingly)
+        ws1 = api.Workspace(ix, max_bytes, args.queries, **dict(ws_kw, concurrent_batches=1))
+        for b in range(min(2, n_distinct)):
+            ws1.search_device(d_bufs[b].data_ptr(), d_offs[b].data_ptr(), args.queries, len(batches[b][0]), stream=streams[0])
+        ws1.finish(streams[0])
+        ws1.set_timing(1)
+        ws1.reset_timers()
         for i in range(96):
             b = i % n_distinct
-            wss[0].search_device(d_bufs[b].data_ptr(), d_offs[b].data_ptr(), args.queries, len(batches[b][0]), stream=streams[0])
+            ws1.search_device(d_bufs[b].data_ptr(), d_offs[b].data_ptr(), args.queries, len(batches[b][0]), stream=streams[0])
             if args.post:
-                wss[0].topn_device(0.05, 10, 10, best_start_codon=nucl, stream=streams[0])
-        wss[0].finish(streams[0])
-        tm_alone = wss[0].kernel_ms_sum()
+                ws1.topn_device(0.05, 10, 10, best_start_codon=nucl, stream=streams[0])
+        ws1.finish(streams[0])
+        tm_alone = ws1.kernel_ms_sum()
+        ws1.close()
 
     exch = None
     if sharded_mode:
@@ -615,7 +635,7 @@ def main():
         "unit": "k-mer lookups/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if sharded_mode else "weak",
         "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-        "config": {"workload": cfg_workload + ("Swiss-Prot-sized synthetic DB" if args.db == "sp" else "Zipf-motif synthetic DB") +
+        "config": {"workload": cfg_workload + ({"sp": "Swiss-Prot-sized synthetic DB", "ur-lite": "DB-SP generator scaled up (ur-lite) synthetic DB"}.get(args.db, "Zipf-motif synthetic DB")) +
                                " (%d proteins, %d residues, %d distinct 7-mers, longest postings list %d) resident in HBM"
                                % (args.db_proteins, int(db[1][-1]), st["n_keys"], st["max_list"]),
                    "queries_per_batch": args.queries, "batches_per_step": args.batches_per_step, "distinct_batches": n_distinct,
@@ -732,6 +752,14 @@ def main():
                     def worker(k):
                         for i in range(per):
                             one_call(k * per + i)
+                    # one untimed round first: a slot creates its workspace, device staging and pinned buffers at its FIRST
+                    # use (hundreds of ms for a 1 M-read chunk).  Round 3 timed that inside the 4-caller case -- the first to
+                    # touch slots 2 and 3 -- and reported 120 ms per call where warmed slots take 12
+                    warm = [threading.Thread(target=one_call, args=(k,)) for k in range(n_thr)]
+                    for t_ in warm:
+                        t_.start()
+                    for t_ in warm:
+                        t_.join()
                     th = [threading.Thread(target=worker, args=(k,)) for k in range(n_thr)]
                     t0 = time.perf_counter()
                     for t_ in th:

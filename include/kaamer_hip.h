@@ -301,6 +301,16 @@ typedef struct {
                              /* the counting kernel wrote it (hit_off[q],      */
                              /* hit_cnt[q] address a sparse array)             */
     uint64_t max_pos_words;  /* u64 words of bitmap storage; 0 = 8 x max_hits  */
+    uint32_t concurrent_batches; /* batches the caller keeps in flight on this  */
+                             /* index at once (other workspaces on other        */
+                             /* streams); 0 / 1: a batch has the device to      */
+                             /* itself.  With 2 or more the counting kernel of   */
+                             /* a protein batch takes ONE workgroup per CU       */
+                             /* instead of three, which leaves registers and     */
+                             /* wave slots for the neighbours' probe kernels:    */
+                             /* -8 % per batch with three in flight, +30 % for a */
+                             /* batch that runs alone                            */
+    uint32_t reserved;
 } kaamer_workspace_opts;
 
 typedef struct {

@@ -65,7 +65,7 @@ class WorkspaceOpts(C.Structure):
     _fields_ = [("max_seq_bytes", C.c_uint64), ("max_seqs", C.c_uint32), ("max_queries", C.c_uint32),
                 ("max_hits", C.c_uint64),
                 ("g_tier_slots", C.c_uint64), ("seq_type", C.c_int32), ("first_pos", C.c_uint32), ("want_positions", C.c_uint32),
-                ("compact", C.c_uint32), ("max_pos_words", C.c_uint64)]
+                ("compact", C.c_uint32), ("max_pos_words", C.c_uint64), ("concurrent_batches", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class DeviceResult(C.Structure):

@@ -645,11 +645,12 @@ class Workspace:
     """Reusable device buffers for the device-resident call."""
 
     def __init__(self, index, max_seq_bytes, max_seqs, max_queries=0, max_hits=0, g_tier_slots=0, seq_type=abi.PROTEIN,
-                 first_pos=0, want_positions=False, max_pos_words=0, compact=False):
+                 first_pos=0, want_positions=False, max_pos_words=0, compact=False, concurrent_batches=0):
         self.index = index
         self.seq_type = seq_type
         o = abi.WorkspaceOpts(max_seq_bytes, max_seqs, max_queries, max_hits,
-                              g_tier_slots, seq_type, first_pos, int(want_positions), int(compact), max_pos_words)
+                              g_tier_slots, seq_type, first_pos, int(want_positions), int(compact), max_pos_words,
+                              int(concurrent_batches), 0)
         h = C.c_void_p()
         abi.check(abi.lib().kaamer_workspace_create(index._h, C.byref(o), C.byref(h)))
         self._h = h

@@ -1710,7 +1710,11 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     if (grp_per_cu < 1) grp_per_cu = 1;
     if (p_per_cu < 1) p_per_cu = 1;
     // tuning knobs (tools/coresident.sh): workgroups per CU of the counting / probe kernels, never above what fits
-    if (const char *e = getenv("KAAMER_GRP_PER_CU")) { const int v = atoi(e); if (v >= 1 && v < grp_per_cu) grp_per_cu = v; }
+    // batches in flight next to this one: ONE counting workgroup per CU (8 waves x 72-80 registers) leaves the CU's other
+    // registers and wave slots to the neighbours' probe kernels; three fill the register file and lock them out
+    // (tools/r4_sweep.sh: 0.134-0.143 ms per batch against 0.148-0.155 with three batches in flight, 0.26 against 0.20 alone)
+    if (opts->concurrent_batches > 1 && !ws->nucleotide) grp_per_cu = 1;
+    if (const char *e = getenv("KAAMER_GRP_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 3) grp_per_cu = v < grp_per_cu || opts->concurrent_batches > 1 ? v : grp_per_cu; }
     if (const char *e = getenv("KAAMER_P_PER_CU")) { const int v = atoi(e); if (v >= 1 && v < p_per_cu) p_per_cu = v; }
     ws->n_cu = prop.multiProcessorCount;
     ws->grp_grid = ws->n_cu * grp_per_cu;

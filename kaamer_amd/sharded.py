@@ -106,7 +106,7 @@ class ShardedSearcher:
 
     def __init__(self, index, rank, world, max_seq_bytes, max_seqs, seq_type=abi.PROTEIN, max_entries_per_peer=1 << 20,
                  group=None, max_hits=0, g_tier_slots=0, first_pos=None, transport="torch", comm=None, adaptive=True,
-                 margin=0.25):
+                 margin=0.25, direct_at_world1=False):
         """first_pos: carry the lowest matching position of every hit through the exchange.  Default: as the reference
         fills PositionHits (search.go:416) -- nucleotide / reads input yes (SetBestStartCodon reads it), protein input no
         (a third less to pack, send, unpack and merge).
@@ -114,7 +114,9 @@ class ShardedSearcher:
         adaptive: size the blocks of a batch from what the batch before last needed (+ margin) instead of the buffers'
         capacity, so that the all-to-all moves payload; the figures come out of the received block headers and are the
         same on every rank (kaamer_exchange_stats).  A batch that does not fit raises KaamerError(E_CAPACITY) from
-        finish() on every rank; `run()` repeats it at full capacity."""
+        finish() on every rank; `run()` repeats it at full capacity.
+        direct_at_world1: with ONE shard the partial lists ARE the results -- skip pack, exchange and merge (the second
+        counting pass) and run the post-steps on the search workspace."""
         assert transport in ("rccl", "torch", "host")
         self.index, self.rank, self.world, self.group = index, rank, world, group
         self.transport = transport
@@ -133,6 +135,7 @@ class ShardedSearcher:
         self.adaptive, self.margin = bool(adaptive), float(margin)
         self._full_next = False    # a batch overflowed its blocks: full capacity until the statistics have caught up
         self.n_steps = 0
+        self.direct = bool(direct_at_world1) and world == 1
         self.mws = api.Workspace(index, 64, L.q_cap, max_queries=L.q_cap, first_pos=fp, max_hits=world * L.e_cap,
                                  g_tier_slots=g_tier_slots)
         n = world * int(L.block_words)
@@ -195,6 +198,14 @@ class ShardedSearcher:
                 e = torch.cuda.Event(enable_timing=True)
                 e.record(stream)
                 ev.append(e)
+        if self.direct:
+            mark()
+            self.last_search = r = self.ws.search_device(d_seqs_ptr, d_off_ptr, n_seqs, seq_bytes, stream=raw)
+            mark(); mark(); mark(); mark()
+            self.last_topn = self.topn(stream, **topn) if topn is not None else None
+            mark()
+            self._account(ev, stream, timed)
+            return r
         if not full:
             self.wire = self._choose_layout()
         else:
@@ -211,18 +222,24 @@ class ShardedSearcher:
         mark()
         self.last_topn = self.topn(stream, **topn) if topn is not None else None
         mark()
-        if timed:
-            stream.synchronize()
-            if self.phase_ms is None:
-                self.phase_ms = dict.fromkeys(PHASES, 0.0)
-                self.phase_ms["batches"] = 0
-            for i, name in enumerate(PHASES):
-                self.phase_ms[name] += ev[i].elapsed_time(ev[i + 1])
-            self.phase_ms["batches"] += 1
+        self._account(ev, stream, timed)
         return r
+
+    def _account(self, ev, stream, timed):
+        if not timed:
+            return
+        stream.synchronize()
+        if self.phase_ms is None:
+            self.phase_ms = dict.fromkeys(PHASES, 0.0)
+            self.phase_ms["batches"] = 0
+        for i, name in enumerate(PHASES):
+            self.phase_ms[name] += ev[i].elapsed_time(ev[i + 1])
+        self.phase_ms["batches"] += 1
 
     def topn(self, stream, min_k_ratio=0.05, min_k_match=10, max_results=10):
         """the post-steps of the reference's drivers on the merged results (SetBestStartCodon for nucleotide input)"""
+        if self.direct:
+            return self.ws.topn_device(min_k_ratio, min_k_match, max_results, best_start_codon=self.nucl, stream=stream.cuda_stream)
         return self.mws.topn_device(min_k_ratio, min_k_match, max_results, best_start_codon=self.nucl,
                                     orf_source=self.ws, q_first=self.rank, q_stride=self.world, stream=stream.cuda_stream)
 
@@ -230,6 +247,9 @@ class ShardedSearcher:
         """-> (counters of the local search, counters of the merge).  BOTH workspaces are finished before an error of
         either is raised: a rank whose own search failed still learns what its merge saw, and a rank whose merge was
         handed a failed peer's blocks raises too (every rank of the batch raises, none hangs at the next collective)."""
+        if self.direct:
+            c = self.ws.finish(stream.cuda_stream)
+            return c, c
         err = None
         out = []
         for w in (self.ws, self.mws):

@@ -247,3 +247,107 @@ def test_makedb_to_hit_entries_end_to_end(klib, oracle, gpu_device):
             assert e["Length"] == len(e["Sequence"]) and e["EntryId"].startswith("sp|P")
             if h["Key"] != int(ids[-1]):    # (the shared last id has two candidate records)
                 assert e["Sequence"].encode() == by_id[h["Key"]]
+
+
+def _embl_text(recs, rng):
+    """UniProt flat-file records around the given sequences (inputEMBL.go:95-113,189-314 read these tags)"""
+    out = []
+    for i, s in enumerate(recs):
+        seq = s.decode()
+        lines = ["ID   P%05d_TEST            Reviewed;       %d AA." % (i, len(seq)),
+                 "AC   P%05d;" % i,
+                 "DE   RecName: Full=Protein number %d {ECO:0000255|HAMAP-Rule:MF_%05d};" % (i, i),
+                 "DE            EC=2.7.%d.1;" % (i % 9 + 1),
+                 "GN   Name=gene%d;" % i,
+                 "OS   Testus organismus (strain %d)." % (i % 7),
+                 "OC   Bacteria; Proteobacteria; Gammaproteobacteria.",
+                 "OX   NCBI_TaxID=%d;" % (100000 + i),
+                 "DR   GO; GO:%07d; F:binding; IEA:UniProtKB-KW." % i,
+                 "DR   KEGG; tst:T%05d; -." % i,
+                 "SQ   SEQUENCE   %d AA;  %d MW;  0000000000000000 CRC64;" % (len(seq), 110 * len(seq))]
+        if rng.random() < 0.05:
+            lines.insert(3, "DE   Flags: Fragment;")         # dropped by the reference (inputEMBL.go:230-233)
+        for k in range(0, len(seq), 60):
+            row = seq[k:k + 60]
+            lines.append("     " + " ".join(row[j:j + 10] for j in range(0, len(row), 10)))
+        lines.append("//")
+        out.append("\n".join(lines) + "\n")
+    return "".join(out).encode()
+
+
+def _gbk_text(recs, rng):
+    """GenPept records (inputGBK.go:94-112,186-301)"""
+    out = []
+    for i, s in enumerate(recs):
+        seq = s.decode().lower()
+        name = "hypothetical protein %d" % i + (", partial" if rng.random() < 0.05 else "")   # ", partial" entries are dropped
+        lines = ["LOCUS       WP_%09d           %d aa            linear   BCT 01-JAN-2020" % (i, len(seq)),
+                 "DEFINITION  %s [Testus organismus]." % name,
+                 "ACCESSION   WP_%09d" % i,
+                 "VERSION     WP_%09d.1" % i,
+                 "KEYWORDS    RefSeq.",
+                 "SOURCE      Testus organismus",
+                 "  ORGANISM  Testus organismus",
+                 "            Bacteria; Proteobacteria.",
+                 "FEATURES             Location/Qualifiers",
+                 "     source          1..%d" % len(seq),
+                 "ORIGIN      "]
+        for k in range(0, len(seq), 60):
+            row = seq[k:k + 60]
+            lines.append("%9d %s" % (k + 1, " ".join(row[j:j + 10] for j in range(0, len(row), 10))))
+        lines.append("//")
+        out.append("\n".join(lines) + "\n")
+    return "".join(out).encode()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["embl", "gbk"])
+def test_flat_file_database_to_hit_entries_end_to_end(klib, oracle, gpu_device, fmt):
+    """SURVEY 8f row 3 on the GPU: UniProt (EMBL) / GenPept (GBK) flat-file text -> kaamer_makedb_embl / _gbk (record-ordinal
+    ids, Fragment / ", partial" filters, the declared-length rule: inputEMBL.go:95-113,189-314, inputGBK.go:94-112,
+    186-301) -> the table built ON THE DEVICE (kaamer_image_build_makedb_device) -> ProteinSearch -> kaamer_fetch_hits.
+    Ids, indexed residues and entries against the line-by-line restatement (oracle/makedb_ref.py); counts against the
+    oracle's index over the restatement's (sequence, id) pairs; once more from the gzipped file (inputEMBL.go:76-84)."""
+    import gzip
+    import importlib.util
+    import os
+    from kaamer_amd import api, search, workload
+    spec = importlib.util.spec_from_file_location("makedb_ref", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "makedb_ref.py"))
+    R = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(R)
+    rng = np.random.default_rng(91)
+    db = workload.make_db(500, seed=79)
+    recs = workload.unpack(db)
+    text = (_embl_text if fmt == "embl" else _gbk_text)(recs, rng)
+    ref = (R.run_embl if fmt == "embl" else R.run_gbk)(text)
+    assert 400 < len(ref) < len(recs)                      # the filters dropped some records; ids keep the record ordinals
+    make = api.Proteins.from_embl if fmt == "embl" else api.Proteins.from_gbk
+    prot = make(text)
+    buf, offs = prot.packed
+    assert [int(i) for i in prot.ids] == [r[0] for r in ref]
+    assert [bytes(buf[int(offs[j]):int(offs[j + 1])]) for j in range(len(ref))] == [r[2] for r in ref]
+    gz = make(gzip.compress(text))
+    assert gz.ids.tolist() == prot.ids.tolist() and bytes(gz.packed[0]) == bytes(buf)
+    img = prot.image(device=gpu_device)
+    assert img.stats() == prot.image().stats()             # device builder == host builder
+    ix = api.Index.from_image(img, gpu_device)
+    oix = oracle.Index.from_proteins([r[2] for r in ref], ids=[r[0] for r in ref])
+    qs = workload.unpack(workload.make_protein_queries(db, 80, seed=80))
+    qtext = "".join(">query%d\n%s\n" % (i, s.decode()) for i, s in enumerate(qs))
+    res = search.FetchHitsInformation(search.ProteinSearch(ix, qtext, search.SearchOptions(MaxResults=5)), prot)
+    assert len(res) > 50
+    by_id = {r[0]: r for r in ref}
+    n_hits = 0
+    for qr in res:
+        q = next(s for i, s in enumerate(qs) if "query%d" % i == qr["Query"]["Name"])
+        pid, km, _ = oix.search(q)
+        full = dict(zip(pid.tolist(), km.tolist()))
+        hits = qr["SearchResults"]["Hits"]
+        assert [h["Kmatch"] for h in hits] == km[:len(hits)].tolist()
+        for h in hits:
+            assert full[h["Key"]] == h["Kmatch"]
+            e, r = qr["HitEntries"][h["Key"]], by_id[h["Key"]]
+            assert e["EntryId"].encode() == r[1] and e["Sequence"].encode() == r[2]
+            assert {k: v for k, v in e["Features"].items() if v} == {k.decode(): v.decode() for k, v in r[4].items() if v}
+            n_hits += 1
+    assert n_hits > 100

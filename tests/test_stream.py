@@ -219,3 +219,32 @@ def test_discarded_tickets_give_their_slots_back(klib, gpu_device):
     ix.close()
     th.join(60)
     assert res and res[0].top_pid.tolist() == ref.top_pid.tolist()
+
+
+@pytest.mark.gpu
+def test_four_callers_after_warm_up_are_not_slower_than_two(klib, gpu_device):
+    """Round 3's bench reported 120 ms per call with exactly four concurrent callers against 20 with two and 12 with eight:
+    the four-caller case was the first to touch slots 2 and 3, and a slot allocates its workspace and pinned staging at
+    first use.  With every slot warmed, four callers must not cost more per call than two (loose bound: timing)."""
+    import threading
+    import time
+    from kaamer_amd import abi, api, workload
+    db = workload.make_db(3000, seed=21)
+    ix = api.Index.from_image(api.Image.from_proteins(packed=db), gpu_device)
+    q = workload.make_reads(db, 200000, seed=22)
+
+    def run(n_thr, per):
+        def worker():
+            for _ in range(per):
+                ix.search_top(packed=q, seq_type=abi.READS)
+        th = [threading.Thread(target=worker) for _ in range(n_thr)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        return (time.perf_counter() - t0) / (n_thr * per)
+
+    run(4, 1)                      # every slot allocates here
+    t2, t4 = run(2, 4), run(4, 4)
+    assert t4 < 2.0 * t2 + 0.005, "per call: 2 callers %.1f ms, 4 callers %.1f ms" % (t2 * 1e3, t4 * 1e3)
