@@ -278,8 +278,11 @@ def main():
     log("DB (%s): %d proteins, %d residues (%.1fs)" % (args.db, args.db_proteins, int(db[1][-1]), time.time() - t0))
     t0 = time.time()
     # the table is built on the device it is searched on (builder_device.hip; byte-identical to the host builder's image)
-    ix = api.Index.from_proteins(packed=db, load_factor=args.load_factor, device=local_rank,
-                                 shard=rank if sharded_mode else 0, n_shards=world if sharded_mode else 1)
+    if os.environ.get("KAAMER_EXP_ARENA_ORDER"):   # experiment: the image comes back to the host and is re-laid there at open time
+        ix = api.Index.from_image(api.Image.from_proteins(packed=db, load_factor=args.load_factor, device=local_rank), local_rank)
+    else:
+        ix = api.Index.from_proteins(packed=db, load_factor=args.load_factor, device=local_rank,
+                                     shard=rank if sharded_mode else 0, n_shards=world if sharded_mode else 1)
     st = ix.stats()
     table_bytes = st["n_buckets"] * BUCKET_BYTES + st["arena_words"] * 4
     log("index built on the device and resident in HBM (%.2f GB) in %.1fs: %s" % (table_bytes / 1e9, time.time() - t0, st))

@@ -283,19 +283,21 @@ template <bool SKIP_IDLE> __global__ __launch_bounds__(64 * P_WAVES) void probe_
 
         // ---- issue: round j serves the lookups of lanes 16j..16j+15, four lanes per 64-byte bucket (16 B each: one
         // fabric sector per probe); nontemporal when the batch is small against the table (a bucket is then read once per
-        // batch; a 1 M-read batch touches every bucket several times and wants them cached)
+        // batch; a 1 M-read batch touches every bucket several times and wants them cached).  Every lane hashes ITS OWN key
+        // once and the rounds pass the bucket index around (the hash per round was computed four times per lookup: 60 of
+        // the loop's 270 VALU instructions per window).
+        uint32_t my_bucket = 0u;
+        if (key != KH_NO_KEY) {
+            my_bucket = (uint32_t)kh_home_bucket(key, p.n_shards, p.n_buckets) + step;
+            my_bucket = my_bucket >= n_buckets ? my_bucket - n_buckets : my_bucket;
+        }
         uint4 ld[4];
-        uint32_t rk[4], rs[4];
+        uint32_t rk[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int src = 16 * j + (int)(lane >> 2);
             rk[j] = __shfl(key, src, 64);
-            rs[j] = __shfl(step, src, 64);
-            uint32_t bucket = 0u;
-            if (rk[j] != KH_NO_KEY) {
-                bucket = (uint32_t)kh_home_bucket(rk[j], p.n_shards, p.n_buckets) + rs[j];
-                bucket = bucket >= n_buckets ? bucket - n_buckets : bucket;
-            }
+            const uint32_t bucket = __shfl(my_bucket, src, 64);
             typedef uint32_t v4u __attribute__((ext_vector_type(4)));
             const v4u *srcp = reinterpret_cast<const v4u *>(p.table) + (uint64_t)bucket * 4 + (lane & 3u);
             if (SKIP_IDLE) {
@@ -310,7 +312,7 @@ template <bool SKIP_IDLE> __global__ __launch_bounds__(64 * P_WAVES) void probe_
             }
         }
         // ---- consume: lane 4g+j ends up owning the lookup of lane 16j+g
-        uint32_t okey = KH_NO_KEY, oval = 0, oempty = 1u, ostep = 0;
+        uint32_t okey = KH_NO_KEY, oval = 0, oempty = 1u;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const uint32_t kk = rk[j];
@@ -321,22 +323,25 @@ template <bool SKIP_IDLE> __global__ __launch_bounds__(64 * P_WAVES) void probe_
             r |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
             e |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)e, 0x4E, 0xf, 0xf, false);
             const bool take = (lane & 3u) == (uint32_t)j;
-            okey = take ? kk : okey; oval = take ? r : oval; oempty = take ? e : oempty; ostep = take ? rs[j] : ostep;
+            okey = take ? kk : okey; oval = take ? r : oval; oempty = take ? e : oempty;
         }
         const uint32_t ooff = __shfl(off, (int)mine, 64);  // position of the lookup this lane owns (window offset, or absolute)
         const bool valid = okey != KH_NO_KEY;
         c_found += (valid && oval != 0u) ? 1u : 0u;
         // the key is not in this bucket and the bucket is full: the lookup goes on one bucket further, from the ring
-        const bool wk = valid && oval == 0u && oempty == 0u && ostep + 1u < n_buckets;
-        const unsigned long long W = __ballot(wk);
+        // (the number of buckets it has walked is fetched only here: a few windows in a hundred get this far)
+        const unsigned long long W = __ballot(valid && oval == 0u && oempty == 0u);
         if (W) {  // wave-uniform; LDS only
+            const uint32_t ostep = __shfl(step, (int)mine, 64);
+            const bool wk = valid && oval == 0u && oempty == 0u && ostep + 1u < n_buckets;
+            const unsigned long long W2 = __ballot(wk);
             if (wk) {
-                const uint32_t slot = (ring_head + ring_n + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(W >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)W, 0u))) & (P_RING - 1u);
+                const uint32_t slot = (ring_head + ring_n + (uint32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(W2 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)W2, 0u))) & (P_RING - 1u);
                 ring_key[slot] = okey;
                 ring_pos[slot] = (uint32_t)base + ooff;  // positions fit 32 bits (checked on the host)
                 ring_step[slot] = ostep + 1u;
             }
-            ring_n += (uint32_t)__popcll(W);
+            ring_n += (uint32_t)__popcll(W2);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1427,6 +1432,7 @@ struct kaamer_workspace {
     uint32_t *d_n_groups;
     uint32_t groups_cap;
     int grp_grid;
+    bool sched_identity;                // groups handed out in index order (no longest-first schedule is built)
     // nucleotide / reads input: 6-frame translation products
     bool nucleotide;
     uint64_t aa_cap, sa_cap;
@@ -1557,8 +1563,46 @@ int kaamer_index_open_image(const kaamer_image *img, int device, kaamer_index **
     int rc = dev_alloc(&ix->d_buckets, (size_t)img->hdr.n_buckets);
     if (!rc) rc = dev_alloc(&ix->d_arena, (size_t)(img->hdr.arena_words < 4 ? 4 : img->hdr.arena_words));
     if (rc) { kaamer_index_close(ix); return rc; }
-    hipError_t e = hipMemcpy(ix->d_buckets, img->buckets, (size_t)img->hdr.n_buckets * sizeof(kh_bucket), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(ix->d_arena, img->arena, (size_t)img->hdr.arena_words * 4, hipMemcpyHostToDevice);
+    const kh_bucket *up_buckets = img->buckets;
+    const uint32_t *up_arena = img->arena;
+    std::vector<kh_bucket> ex_buckets;
+    std::vector<uint32_t> ex_arena;
+    if (const char *ev = getenv("KAAMER_EXP_ARENA_ORDER")) {
+        // EXPERIMENT (tools/r4_arena_order.sh), not a product path: the postings lists re-ordered before the upload, to
+        // measure what locality between the lists of one protein's k-mers is worth.  1 = by (first id, old offset)
+        struct Ref { uint32_t first_id, off; };
+        std::vector<Ref> refs;
+        const uint64_t nb = img->hdr.n_buckets;
+        for (uint64_t b = 0; b < nb; b++)
+            for (int t = 0; t < KH_SLOTS_PER_BUCKET; t++) {
+                const kh_slot &sl = img->buckets[b].s[t];
+                if (sl.key != KH_EMPTY_KEY && !(sl.val & KH_INLINE_BIT) && sl.val) refs.push_back(Ref{ img->arena[(uint64_t)sl.val * 4 + 1], sl.val });
+            }
+        std::sort(refs.begin(), refs.end(), [](const Ref &a, const Ref &b) { return a.off < b.off; });
+        refs.erase(std::unique(refs.begin(), refs.end(), [](const Ref &a, const Ref &b) { return a.off == b.off; }), refs.end());
+        if (atoi(ev) == 1) std::stable_sort(refs.begin(), refs.end(), [](const Ref &a, const Ref &b) { return a.first_id < b.first_id; });
+        ex_arena.assign((size_t)img->hdr.arena_words, 0u);
+        std::vector<uint32_t> new_off((size_t)(img->hdr.arena_words / 4 + 1), 0u);
+        uint32_t cur = 1;   // unit 0 is "no list"
+        for (const Ref &r : refs) {
+            const uint32_t cnt = img->arena[(uint64_t)r.off * 4];
+            const uint32_t units = (1u + cnt + 3u) / 4u;
+            memcpy(&ex_arena[(size_t)cur * 4], &img->arena[(size_t)r.off * 4], (size_t)units * 16);
+            new_off[r.off] = cur;
+            cur += units;
+        }
+        ex_buckets.assign(img->buckets, img->buckets + nb);
+        for (uint64_t b = 0; b < nb; b++)
+            for (int t = 0; t < KH_SLOTS_PER_BUCKET; t++) {
+                kh_slot &sl = ex_buckets[b].s[t];
+                if (sl.key != KH_EMPTY_KEY && !(sl.val & KH_INLINE_BIT) && sl.val) sl.val = new_off[sl.val];
+            }
+        fprintf(stderr, "[kaamer experiment] arena re-ordered (%zu lists, %u units of %llu)\n", refs.size(), cur, (unsigned long long)(img->hdr.arena_words / 4));
+        up_buckets = ex_buckets.data();
+        up_arena = ex_arena.data();
+    }
+    hipError_t e = hipMemcpy(ix->d_buckets, up_buckets, (size_t)img->hdr.n_buckets * sizeof(kh_bucket), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(ix->d_arena, up_arena, (size_t)img->hdr.arena_words * 4, hipMemcpyHostToDevice);
     // list offset 0 is never handed out (kaamer_layout.h) and reads as "no list": the counting kernel loads it for
     // positions without a list instead of branching around the load (count_pack.hip.inc)
     if (e == hipSuccess) e = hipMemset(ix->d_arena, 0, 16);
@@ -1714,6 +1758,8 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     // registers and wave slots to the neighbours' probe kernels; three fill the register file and lock them out
     // (tools/r4_sweep.sh: 0.134-0.143 ms per batch against 0.148-0.155 with three batches in flight, 0.26 against 0.20 alone)
     if (opts->concurrent_batches > 1 && !ws->nucleotide) grp_per_cu = 1;
+    ws->sched_identity = opts->concurrent_batches > 1;
+    if (const char *e = getenv("KAAMER_SCHED_IDENTITY")) ws->sched_identity = atoi(e) != 0;
     if (const char *e = getenv("KAAMER_GRP_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 3) grp_per_cu = v < grp_per_cu || opts->concurrent_batches > 1 ? v : grp_per_cu; }
     if (const char *e = getenv("KAAMER_P_PER_CU")) { const int v = atoi(e); if (v >= 1 && v < p_per_cu) p_per_cu = v; }
     ws->n_cu = prop.multiProcessorCount;
@@ -1963,7 +2009,10 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         pl.status = status; pl.sched = ws->d_sched; pl.d_n_sched = ws->d_n_sched;
         pl.tiles_done = ws->d_list_counts + SLOT_TILES_DONE;
         pl.slots = ws->d_slots; pl.bshift = ws->pack_shift; pl.cshift = ws->pack_shift >= GRP_SHIFT ? 9u : 7u;
-        pl.no_sched = ws->use_group ? 0u : 1u;
+        // the longest-first schedule is built by the LAST tile of this launch, alone, in some twenty dependent rounds of
+        // loads: worth it when the batch has the device to itself (3.5 groups per workgroup: -6 us of stragglers), not when a
+        // workgroup per CU takes ~10 groups each next to other batches
+        pl.no_sched = (ws->use_group && !ws->sched_identity) ? 0u : 1u;
         pl.d_total = ws->d_lay_total;
         pl.slot_scale = ws->d_slot_scale;
         const uint32_t tiles = (uint32_t)(((uint64_t)n_seqs + 1 + PL_TILE - 1) / PL_TILE);
