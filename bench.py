@@ -571,7 +571,7 @@ def main():
     # when this run is the workload those passes measured
     traffic = None
     requests = None   # 64-byte fabric requests per batch, from the same PMC passes (FETCH_SIZE + WRITE_SIZE count them)
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", rnd + "_pmc_traffic.json")))
         except Exception:
