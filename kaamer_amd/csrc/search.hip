@@ -1758,7 +1758,9 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     // registers and wave slots to the neighbours' probe kernels; three fill the register file and lock them out
     // (tools/r4_sweep.sh: 0.134-0.143 ms per batch against 0.148-0.155 with three batches in flight, 0.26 against 0.20 alone)
     if (opts->concurrent_batches > 1 && !ws->nucleotide) grp_per_cu = 1;
-    ws->sched_identity = opts->concurrent_batches > 1;
+    // (measured with one workgroup per CU and three batches in flight, same box, A/B/A/B: 0.1381-0.1406 ms per batch with the
+    // longest-first schedule, 0.1430-0.1441 with the groups in index order: the schedule stays)
+    ws->sched_identity = false;
     if (const char *e = getenv("KAAMER_SCHED_IDENTITY")) ws->sched_identity = atoi(e) != 0;
     if (const char *e = getenv("KAAMER_GRP_PER_CU")) { const int v = atoi(e); if (v >= 1 && v <= 3) grp_per_cu = v < grp_per_cu || opts->concurrent_batches > 1 ? v : grp_per_cu; }
     if (const char *e = getenv("KAAMER_P_PER_CU")) { const int v = atoi(e); if (v >= 1 && v < p_per_cu) p_per_cu = v; }
@@ -2009,9 +2011,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         pl.status = status; pl.sched = ws->d_sched; pl.d_n_sched = ws->d_n_sched;
         pl.tiles_done = ws->d_list_counts + SLOT_TILES_DONE;
         pl.slots = ws->d_slots; pl.bshift = ws->pack_shift; pl.cshift = ws->pack_shift >= GRP_SHIFT ? 9u : 7u;
-        // the longest-first schedule is built by the LAST tile of this launch, alone, in some twenty dependent rounds of
-        // loads: worth it when the batch has the device to itself (3.5 groups per workgroup: -6 us of stragglers), not when a
-        // workgroup per CU takes ~10 groups each next to other batches
+        // (KAAMER_SCHED_IDENTITY=1: no longest-first schedule, groups in index order -- an A/B knob)
         pl.no_sched = (ws->use_group && !ws->sched_identity) ? 0u : 1u;
         pl.d_total = ws->d_lay_total;
         pl.slot_scale = ws->d_slot_scale;
