@@ -637,6 +637,53 @@ int32_t kaamer_set_best_start_codon(const uint32_t *kmatch_sorted, const uint32_
                                     int32_t *start_position, int32_t *size_in_kmer);
 
 /* ------------------------------------------------------------------------- */
+/* Alignment of the reported hits (`-aln`) — replaces, for all (query, hit) pairs */
+/* of a batch at once, the loop of QueryResultHandler (search.go:483-494) over     */
+/* align.Align (pkg/align/align.go:46-161): local alignment with affine gaps on    */
+/* the device (one lane per pair), then the reference's own arithmetic on the host: */
+/* Identity / Similarity (float32), Length, Mismatches, GapOpenings, Raw, BitScore  */
+/* = (lambda * Raw - ln K) / ln 2, EValue = len(query) * NumberOfAA / 2^BitScore,    */
+/* the 1-based inclusive coordinates and AlnString's three rows.                    */
+/* The aligner itself is github.com/biogo/biogo v1.0.1 (align.SWAffine on          */
+/* matrix.BLOSUM62 with GapOpen -11, align.go:62-67 -- fixed, whatever the options   */
+/* are), which is not part of the reference tree: the recurrence is restated from    */
+/* its published algorithm and its tie-breaking is not pinned by anything in the     */
+/* reference.                                                  */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+    float identity, similarity;   /* AlignmentResult.Identity / .Similarity (percent, float32)     */
+    int32_t length;               /* columns of the alignment = len of each row of AlnString        */
+    int32_t mismatches, gap_openings, raw;
+    double bitscore, evalue;
+    int32_t query_start, query_end, subject_start, subject_end;   /* 1-based, inclusive             */
+    uint64_t aln_off;             /* into kaamer_alignments_text: query row, match row, subject row, */
+                                  /* `length` bytes each (AlnString joins them with '\n')            */
+    int32_t status;               /* 0 aligned; 1 "No matrix found" (GetMatrixScores: the reference  */
+                                  /* keeps an empty AlignmentResult; also any matrix but BLOSUM62,    */
+                                  /* whose data the similarity marks need); 2 a letter outside the    */
+                                  /* protein alphabet "-ABCDEFGHIJKLMNPQRSTVWXYZ*" (SWAffine fails);   */
+                                  /* 3 a sequence too long                                            */
+    int32_t reserved;
+} kaamer_alignment;
+typedef struct kaamer_alignments kaamer_alignments;
+/* pair i aligns sequence pair_query[i] (the Query.Sequence) with sequence pair_subject[i] (the hit's Protein.Sequence) of
+ * the packed buffer (seqs, offsets[n_seqs + 1]); number_of_aa = KStats.NumberOfAA (kaamer_proteins_stats); sub_matrix /
+ * gap_open / gap_extend = SearchOptions.SubMatrix / GapOpen / GapExtend (defaults "blosum62", 11, 1: api/server.go:149-151).
+ * All caller buffers are direct arguments (cgo-safe).  Results in pair order. */
+int kaamer_align_pairs(int device, const uint8_t *seqs, const uint64_t *offsets, uint32_t n_seqs,
+                       const uint32_t *pair_query, const uint32_t *pair_subject, uint32_t n_pairs,
+                       uint64_t number_of_aa, const char *sub_matrix, int32_t gap_open, int32_t gap_extend,
+                       kaamer_alignments **out);
+uint32_t kaamer_alignments_count(const kaamer_alignments *a);
+const kaamer_alignment *kaamer_alignments_items(const kaamer_alignments *a);
+const char *kaamer_alignments_text(const kaamer_alignments *a);
+void kaamer_alignments_free(kaamer_alignments *a);
+/* GetMatrixScores (matrixScores.go:107-115): KAAMER_E_ARG ("No matrix found") when the table has no such row */
+int kaamer_align_matrix_scores(const char *sub_matrix, int32_t gap_open, int32_t gap_extend, double *lambda, double *k);
+/* GetAlnScoreAA on BLOSUM62 (matrixScores.go:125-127): letters of AAPosInMatrix, anything else reads as '-' */
+int32_t kaamer_align_matrix_entry(int32_t a, int32_t b);
+
+/* ------------------------------------------------------------------------- */
 /* Readers — GetQueriesFasta / GetQueriesFastq (search.go:222-412) on a text   */
 /* buffer (already decompressed): packed sequences + SizeInKmer + names, with  */
 /* the reference's quirks (every FASTA record but the last is upper-cased; '*' */

@@ -101,6 +101,13 @@ class ProteinEntry(C.Structure):
                 ("n_features", C.c_uint32), ("sequence", C.c_void_p), ("features", C.c_void_p), ("feature_off", C.POINTER(C.c_uint64))]
 
 
+class Alignment(C.Structure):
+    _fields_ = [("identity", C.c_float), ("similarity", C.c_float), ("length", C.c_int32), ("mismatches", C.c_int32),
+                ("gap_openings", C.c_int32), ("raw", C.c_int32), ("bitscore", C.c_double), ("evalue", C.c_double),
+                ("query_start", C.c_int32), ("query_end", C.c_int32), ("subject_start", C.c_int32), ("subject_end", C.c_int32),
+                ("aln_off", C.c_uint64), ("status", C.c_int32), ("reserved", C.c_int32)]
+
+
 class TopnResult(C.Structure):
     _fields_ = [("max_results", C.c_uint32), ("d_top_cnt", C.c_void_p), ("d_top_pid", C.c_void_p),
                 ("d_top_kmatch", C.c_void_p), ("d_top_first_pos", C.c_void_p), ("d_trim", C.c_void_p),
@@ -226,6 +233,14 @@ SYMBOLS = {
     "kaamer_replica_stream_close": (None, [C.c_void_p]),
     "kaamer_search_file": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int32, C.c_double, C.c_int64, C.c_uint32, C.c_uint32,
                                      C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(Counters)]),
+    "kaamer_align_pairs": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64,
+                                     C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "kaamer_alignments_count": (C.c_uint32, [C.c_void_p]),
+    "kaamer_alignments_items": (C.POINTER(Alignment), [C.c_void_p]),
+    "kaamer_alignments_text": (C.POINTER(C.c_char), [C.c_void_p]),
+    "kaamer_alignments_free": (None, [C.c_void_p]),
+    "kaamer_align_matrix_scores": (C.c_int, [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "kaamer_align_matrix_entry": (C.c_int32, [C.c_int32, C.c_int32]),
     "kaamer_reader_open": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "kaamer_reader_open_fd": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "kaamer_reader_next": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(C.c_void_p)]),

@@ -827,3 +827,37 @@ def parse_reads(text, fmt="fasta"):
                 for i in range(n)]
     finally:
         abi.lib().kaamer_reads_free(h)
+
+
+def align_pairs(seqs=None, packed=None, pairs=(), number_of_aa=0, sub_matrix="blosum62", gap_open=11, gap_extend=1, device=0):
+    """kaamer_align_pairs: align.Align (align.go:46-161) for every (query index, subject index) pair -> list of dicts
+    (None where the reference keeps an empty AlignmentResult: "No matrix found"; a ValueError-like status is returned as
+    {"status": n})"""
+    buf, offs = packed if packed is not None else pack_sequences(seqs)
+    buf = np.ascontiguousarray(buf, dtype=np.uint8)
+    offs = np.ascontiguousarray(offs, dtype=np.uint64)
+    pq = np.ascontiguousarray([p[0] for p in pairs], dtype=np.uint32)
+    ps = np.ascontiguousarray([p[1] for p in pairs], dtype=np.uint32)
+    h = C.c_void_p()
+    L = abi.lib()
+    abi.check(L.kaamer_align_pairs(device, buf.ctypes.data if len(buf) else None, offs.ctypes.data, len(offs) - 1,
+                                   pq.ctypes.data if len(pq) else None, ps.ctypes.data if len(ps) else None, len(pq), int(number_of_aa),
+                                   sub_matrix.encode(), gap_open, gap_extend, C.byref(h)))
+    try:
+        n = L.kaamer_alignments_count(h)
+        items = L.kaamer_alignments_items(h)
+        text = L.kaamer_alignments_text(h)
+        out = []
+        for i in range(n):
+            a = items[i]
+            if a.status == 1:
+                out.append(None)
+                continue
+            d = {k: getattr(a, k) for k, _ in abi.Alignment._fields_ if k not in ("aln_off", "reserved")}
+            ln, off = a.length, a.aln_off
+            raw = C.string_at(C.addressof(text.contents) + off, 3 * ln) if ln else b""
+            d["aln"] = (raw[:ln].decode("latin-1"), raw[ln:2 * ln].decode("latin-1"), raw[2 * ln:].decode("latin-1"))
+            out.append(d)
+        return out
+    finally:
+        L.kaamer_alignments_free(h)

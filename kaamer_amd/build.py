@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libkaamer_hip.so")
-SOURCES = ["search.hip", "builder_device.hip", "builder.cpp", "host_search.cpp", "makedb.cpp"]
+SOURCES = ["search.hip", "builder_device.hip", "align.hip", "builder.cpp", "host_search.cpp", "makedb.cpp"]
 # every header / included kernel file: an edit to any of them rebuilds the library
 HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))) + [os.path.join("..", "..", "include", "kaamer_hip.h")]
 ARCH = "gfx950"

@@ -23,6 +23,10 @@ class SearchOptions:  # search.go:56-71 (the fields the hot path reads); default
     MinKMatch: int = 10
     MinKRatio: float = 0.05
     ExtractPositions: bool = False
+    Align: bool = False           # search.go:65; the alignment step: AlignHits below
+    SubMatrix: str = "blosum62"   # api/server.go:149-151
+    GapOpen: int = 11
+    GapExtend: int = 1
 
 
 def _sorted_hits(res, q):
@@ -158,4 +162,47 @@ def FetchHitsInformation(query_results, proteins):
             he[h["Key"]] = {"EntryId": e["EntryId"].decode("latin-1"), "Sequence": e["Sequence"].decode("latin-1"),
                             "Length": e["Length"],
                             "Features": {k.decode("latin-1"): v.decode("latin-1") for k, v in e["Features"].items()}}
+    return query_results
+
+
+def AlignHits(query_results, proteins, opts, device=0):
+    """The alignment step of QueryResultHandler (search.go:483-494) for a list of QueryResult dicts that went through
+    FetchHitsInformation: align.Align(Query.Sequence, HitEntries[hit.Key].Sequence, dbStats, SubMatrix, GapOpen,
+    GapExtend) for every reported hit -- all pairs of the batch in ONE device call (kaamer_align_pairs) -- then the hits
+    of each query re-sorted by BitScore, descending.  A pair for which Align returns an error ("No matrix found") keeps
+    the empty AlignmentResult sortMapByValue gave it (search.go:144)."""
+    seqs, index, pairs, where = [], {}, [], []
+
+    def seq_id(s):
+        if s not in index:
+            index[s] = len(seqs)
+            seqs.append(s)
+        return index[s]
+    for qi, qr in enumerate(query_results):
+        q = qr["Query"]["Sequence"].encode("latin-1")
+        for hi, h in enumerate(qr["SearchResults"]["Hits"]):
+            e = qr.get("HitEntries", {}).get(h["Key"])
+            if e is None:
+                continue
+            pairs.append((seq_id(q), seq_id(e["Sequence"].encode("latin-1"))))
+            where.append((qi, hi))
+    empty = {"Identity": 0.0, "Similarity": 0.0, "Length": 0, "Mismatches": 0, "GapOpenings": 0, "Raw": 0, "BitScore": 0.0,
+             "EValue": 0.0, "AlnString": "", "QueryStart": 0, "QueryEnd": 0, "SubjectStart": 0, "SubjectEnd": 0}
+    for qr in query_results:
+        for h in qr["SearchResults"]["Hits"]:
+            h["Alignment"] = dict(empty)
+    if pairs:
+        n_aa = proteins.stats()[1]   # KStats.NumberOfAA
+        got = api.align_pairs(seqs=seqs, pairs=pairs, number_of_aa=n_aa, sub_matrix=getattr(opts, "SubMatrix", "blosum62"),
+                              gap_open=getattr(opts, "GapOpen", 11), gap_extend=getattr(opts, "GapExtend", 1), device=device)
+        for (qi, hi), a in zip(where, got):
+            if a is None or a.get("status"):
+                continue
+            query_results[qi]["SearchResults"]["Hits"][hi]["Alignment"] = {
+                "Identity": a["identity"], "Similarity": a["similarity"], "Length": a["length"], "Mismatches": a["mismatches"],
+                "GapOpenings": a["gap_openings"], "Raw": a["raw"], "BitScore": a["bitscore"], "EValue": a["evalue"],
+                "AlnString": "\n".join(a["aln"]), "QueryStart": a["query_start"], "QueryEnd": a["query_end"],
+                "SubjectStart": a["subject_start"], "SubjectEnd": a["subject_end"]}
+    for qr in query_results:   # sort.Slice by BitScore descending (search.go:492-494; ties keep their order here)
+        qr["SearchResults"]["Hits"].sort(key=lambda h: -h["Alignment"]["BitScore"])
     return query_results

@@ -16,8 +16,8 @@ _SO = os.path.join(_HERE, "libkaamer_oracle.so")
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "kaamer_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("kaamer_oracle.c", "align_oracle.c")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libkaamer_oracle.so"])
     return _SO
 
@@ -269,3 +269,54 @@ def set_best_start_codon(kmatch, pos, size, starts_alt, plus, seq, start_positio
     t = lib().ko_set_best_start_codon(km.ctypes.data, len(km), p.ctypes.data, size, sa.ctypes.data,
                                       len(sa), int(plus), s, len(s), C.byref(sp), C.byref(so))
     return int(t), int(sp.value), int(so.value)
+
+
+# ---- the alignment step (-aln): oracle/align_oracle.c ------------------------------------------------------
+class _Alignment(C.Structure):
+    _fields_ = [("identity", C.c_float), ("similarity", C.c_float), ("length", C.c_int32), ("mismatches", C.c_int32),
+                ("gap_openings", C.c_int32), ("raw", C.c_int32), ("bitscore", C.c_double), ("evalue", C.c_double),
+                ("q_start", C.c_int32), ("q_end", C.c_int32), ("s_start", C.c_int32), ("s_end", C.c_int32)]
+
+
+def matrix_scores(sub_matrix, gap_open, gap_extend):
+    """GetMatrixScores (matrixScores.go:107-115) -> (lambda, K) or None ("No matrix found")"""
+    L = lib()
+    L.ko_matrix_scores.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lam, k = C.c_double(), C.c_double()
+    if L.ko_matrix_scores(sub_matrix.encode(), gap_open, gap_extend, C.byref(lam), C.byref(k)):
+        return None
+    return lam.value, k.value
+
+
+def b62(a, b, gap_col=0):
+    """matrix.BLOSUM62 by letters of "-ABCDEFGHIJKLMNPQRSTVWXYZ*" """
+    L = lib()
+    L.ko_b62.argtypes = [C.c_int, C.c_int, C.c_int]
+    alpha = "-ABCDEFGHIJKLMNPQRSTVWXYZ*"
+    return L.ko_b62(alpha.index(a), alpha.index(b), gap_col)
+
+
+def align(query, subject, number_of_aa, sub_matrix="blosum62", gap_open=11, gap_extend=1, dp_gap_open=-11, gap_col=0):
+    """align.Align (align.go:46-161) -> dict, or None for "No matrix found"; raises ValueError on a letter outside the
+    alphabet"""
+    L = lib()
+    L.ko_align.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_int, C.c_uint64, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                           C.POINTER(_Alignment), C.c_char_p, C.POINTER(C.c_int)]
+    q = query if isinstance(query, bytes) else query.encode("latin-1")
+    s = subject if isinstance(subject, bytes) else subject.encode("latin-1")
+    out = _Alignment()
+    buf = C.create_string_buffer(3 * (len(q) + len(s)) + 8)
+    n = C.c_int()
+    rc = L.ko_align(q, len(q), s, len(s), int(number_of_aa), sub_matrix.encode(), gap_open, gap_extend, dp_gap_open, gap_col,
+                    C.byref(out), buf, C.byref(n))
+    if rc == 1:
+        return None
+    if rc == 2:
+        raise ValueError("letter outside the protein alphabet")
+    if rc:
+        raise MemoryError()
+    ln = n.value
+    raw = buf.raw
+    d = {k: getattr(out, k) for k, _ in _Alignment._fields_}
+    d["aln"] = (raw[:ln].decode("latin-1"), raw[ln:2 * ln].decode("latin-1"), raw[2 * ln:3 * ln].decode("latin-1"))
+    return d

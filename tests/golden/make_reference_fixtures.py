@@ -10,6 +10,8 @@ Outputs (data only: inputs and expected outputs, no reference source text):
                        gcodeBacteria in pkg/search/gcode.go:36-101
   docs_example.json    the worked protein-search example of docs/client.md:131-180
                        (query sequence, SizeInKmer, hit Kmatch, PositionHits length)
+  matrix_scores.json   "<matrix>_<open>_<extend>" -> [lambda, K] and the letter -> index map AAPosInMatrix, parsed from
+                       the literals of pkg/align/matrixScores.go:22-117
 """
 import json
 import os
@@ -47,7 +49,22 @@ def docs_example():
                 start_position=1, end_position=int(re.search(r'"EndPosition": (\d+)', js).group(1)))
 
 
+def matrix_scores():
+    src = open(os.path.join(REF, "pkg/align/matrixScores.go")).read()
+    rows = re.findall(r'"([a-z0-9]+_\d+_\d+)":\s*MatrixScores\{SubMatrix: matrix\.([A-Z0-9]+), GapOpen: (\d+), GapExtend: (\d+), Lambda: ([0-9.]+), K: ([0-9.]+)\}', src)
+    table = {}
+    for key, mat, go, ge, lam, k in rows:
+        assert key == "%s_%s_%s" % (mat.lower(), go, ge), key
+        table[key] = [float(lam), float(k)]
+    assert len(table) == len(rows) > 80
+    pos = re.search(r"AAPosInMatrix = map\[rune\]int\{(.*?)\}", src, re.S).group(1)
+    aa = {m[0]: int(m[1]) for m in re.findall(r"'(.)': (\d+)", pos)}
+    assert len(aa) == 26
+    return {"lambda_k": table, "aa_pos_in_matrix": aa}
+
+
 if __name__ == "__main__":
+    json.dump(matrix_scores(), open(os.path.join(HERE, "matrix_scores.json"), "w"), indent=0, sort_keys=True)
     json.dump(gcode(), open(os.path.join(HERE, "gcode_bacteria.json"), "w"), indent=0, sort_keys=True)
     json.dump(docs_example(), open(os.path.join(HERE, "docs_example.json"), "w"), indent=1, sort_keys=True)
     print("ok")

@@ -5,7 +5,7 @@ set -o pipefail
 NAME=$1; FLAGS=$2; shift 2
 mkdir -p build gpurun_out
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-function $FLAGS -o build/libkaamer_$NAME.so \
-  kaamer_amd/csrc/search.hip kaamer_amd/csrc/builder_device.hip kaamer_amd/csrc/builder.cpp kaamer_amd/csrc/host_search.cpp kaamer_amd/csrc/makedb.cpp -lpthread -lz 2> gpurun_out/variant_$NAME.build.log || { tail -5 gpurun_out/variant_$NAME.build.log; exit 1; }
+  kaamer_amd/csrc/search.hip kaamer_amd/csrc/builder_device.hip kaamer_amd/csrc/align.hip kaamer_amd/csrc/builder.cpp kaamer_amd/csrc/host_search.cpp kaamer_amd/csrc/makedb.cpp -lpthread -lz 2> gpurun_out/variant_$NAME.build.log || { tail -5 gpurun_out/variant_$NAME.build.log; exit 1; }
 for v in shipped $NAME; do
   lib=""; [ $v != shipped ] && lib="$PWD/build/libkaamer_$NAME.so"
   KAAMER_LIB=$lib python bench.py --no-cpu-baseline --check 0 "$@" > gpurun_out/variant_${NAME}_$v.json 2> gpurun_out/variant_${NAME}_$v.log || { tail -5 gpurun_out/variant_${NAME}_$v.log; exit 1; }
