@@ -192,7 +192,7 @@ def AlignHits(query_results, proteins, opts, device=0):
         for h in qr["SearchResults"]["Hits"]:
             h["Alignment"] = dict(empty)
     if pairs:
-        n_aa = proteins.stats()[1]   # KStats.NumberOfAA
+        n_aa = proteins.stats()["NumberOfAA"]   # KStats.NumberOfAA (kvstore.KStats)
         got = api.align_pairs(seqs=seqs, pairs=pairs, number_of_aa=n_aa, sub_matrix=getattr(opts, "SubMatrix", "blosum62"),
                               gap_open=getattr(opts, "GapOpen", 11), gap_extend=getattr(opts, "GapExtend", 1), device=device)
         for (qi, hi), a in zip(where, got):

@@ -175,7 +175,7 @@ def test_search_then_align_like_query_result_handler(klib, oracle, gpu_device):
     qtext = "".join(">q%d\n%s\n" % (i, s.decode()) for i, s in enumerate(qs))
     res = search.FetchHitsInformation(search.ProteinSearch(ix, qtext, search.SearchOptions(MaxResults=5)), prot)
     res = search.AlignHits(res, prot, search.SearchOptions(MaxResults=5), device=gpu_device)
-    n_aa = prot.stats()[1]
+    n_aa = prot.stats()["NumberOfAA"]
     n = 0
     for qr in res:
         hits = qr["SearchResults"]["Hits"]
