@@ -182,10 +182,12 @@ struct KeyArrays {
     const uint64_t *pairs;   // sorted, unique
     const uint32_t *kstart;  // [n_keys + 1]
     uint32_t n_keys;
-    uint64_t *tab_hash;      // [cap] 0 = empty
-    uint32_t *tab_rep;       // [cap] smallest key index with that hash
-    uint32_t tab_mask;
-    uint32_t *slot_of;       // [n_keys] table slot of a list key
+    uint64_t *hv;            // [n_keys] content hash of a list key's set (0: the key stores its id inline)
+    uint32_t *hk;            // [n_keys] key index (the value of the sort by hash)
+    const uint64_t *hv_s;    // the two arrays sorted by hash (stable: within a hash, ascending key index)
+    const uint32_t *hk_s;
+    const uint32_t *run_start;  // [n_keys] sorted position of the first element with the same hash
+    uint32_t *rep_of;        // [n_keys] representative of a list key's set = the smallest key index with its hash
     uint32_t *units;         // [n_keys] 16-byte units a key ADDS to the arena
     uint32_t *uoff;          // [n_keys] exclusive prefix of units, from 1
     uint32_t *arena;
@@ -204,7 +206,10 @@ __device__ inline bool key_is_inline(const KeyArrays &a, uint32_t k, uint32_t &s
     return c == 1 && (uint32_t)a.pairs[s] < KH_INLINE_BIT;
 }
 
-// pass 1: content hash of every postings set into the table; the smallest key index of a hash is its representative
+// pass 1: content hash of every postings set.  The representative of a set is the smallest key index that carries its hash:
+// the keys are SORTED by hash (a stable radix sort: equal hashes stay in key order) and the head of every run is the
+// representative.  (Rounds 2-3 found it with a compare-and-swap into an open-addressed table + atomicMin per key: 93 ms of
+// the 0.3 s DB-SP build went into those contended atomics; the sort is ~10 ms.)
 __global__ __launch_bounds__(256) void bd_hash_kernel(KeyArrays a)
 {
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
@@ -213,23 +218,18 @@ __global__ __launch_bounds__(256) void bd_hash_kernel(KeyArrays a)
         uint32_t s, c;
         const bool inl = key_is_inline(a, k, s, c);
         mpid = (uint32_t)a.pairs[s + c - 1];
+        uint64_t h = 0;
         if (inl) n_inline = 1;
         else {
             ub = (1ull + c + 3ull) / 4ull;
             mx = c;
-            uint64_t h = a.seed ^ c;
-            // seed 0 (tests only): the hash is the set's size, so unequal sets meet in the table
+            h = a.seed ^ c;
+            // seed 0 (tests only): the hash is the set's size, so unequal sets meet
             for (uint32_t t = 0; a.seed && t < c; t++) h = bd_mix64(h + (uint32_t)a.pairs[s + t] * 0x9E3779B97F4A7C15ull);
             if (!h) h = 1;
-            uint32_t slot = (uint32_t)h & a.tab_mask;
-            for (;;) {
-                const unsigned long long old = atomicCAS((unsigned long long *)&a.tab_hash[slot], 0ull, (unsigned long long)h);
-                if (old == 0ull || old == h) break;
-                slot = (slot + 1) & a.tab_mask;
-            }
-            atomicMin(&a.tab_rep[slot], k);
-            a.slot_of[k] = slot;
         }
+        a.hv[k] = h;
+        a.hk[k] = k;
     }
     n_inline = wave_sum(n_inline); ub = wave_sum(ub); mx = wave_max(mx); mpid = wave_max(mpid);
     if ((threadIdx.x & 63u) == 0) {
@@ -240,6 +240,22 @@ __global__ __launch_bounds__(256) void bd_hash_kernel(KeyArrays a)
     }
 }
 
+// sorted position i -> i if it is the first of its hash, else 0 (an inclusive max-scan turns that into the run's start)
+struct RunHead {
+    const uint64_t *hv_s;
+    __device__ uint32_t operator()(uint32_t i) const { return (i == 0 || hv_s[i] != hv_s[i - 1]) ? i : 0u; }
+};
+struct MaxU32 {
+    __host__ __device__ uint32_t operator()(uint32_t x, uint32_t y) const { return x > y ? x : y; }
+};
+
+__global__ __launch_bounds__(256) void bd_rep_kernel(KeyArrays a)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= a.n_keys || a.hv_s[i] == 0) return;
+    a.rep_of[a.hk_s[i]] = a.hk_s[a.run_start[i]];
+}
+
 // pass 2: representatives take arena space; everyone else proves it holds the representative's set
 __global__ __launch_bounds__(256) void bd_share_kernel(KeyArrays a)
 {
@@ -248,7 +264,7 @@ __global__ __launch_bounds__(256) void bd_share_kernel(KeyArrays a)
     if (k < a.n_keys) {
         uint32_t s, c, u = 0;
         if (!key_is_inline(a, k, s, c)) {
-            const uint32_t rep = a.tab_rep[a.slot_of[k]];
+            const uint32_t rep = a.rep_of[k];
             if (rep == k) { u = (1u + c + 3u) / 4u; n_lists = 1; }
             else {
                 const uint32_t rs = a.kstart[rep], rc = a.kstart[rep + 1] - rs;
@@ -272,7 +288,7 @@ __global__ __launch_bounds__(256) void bd_lists_kernel(KeyArrays a)
     const uint32_t key = (uint32_t)(a.pairs[a.kstart[k]] >> 32);
     if (key_is_inline(a, k, s, c)) val = KH_INLINE_BIT | (uint32_t)a.pairs[s];
     else {
-        const uint32_t rep = a.tab_rep[a.slot_of[k]];
+        const uint32_t rep = a.rep_of[k];
         val = a.uoff[rep];
         if (rep == k) {
             uint32_t *l = a.arena + (uint64_t)val * 4;
@@ -506,28 +522,43 @@ int kaamer_build_on_device(const uint8_t *seqs, const uint64_t *offsets, const u
         a.n_buckets = n_buckets;
         a.n_shards = n_shards;
         a.st = st;
-        DevMem d_slot_of, d_units, d_uoff, d_tab_hash, d_tab_rep, d_pkeys, d_pkeys_alt, d_pvals, d_pvals_alt;
-        BD_HIP(d_slot_of.alloc((size_t)n_keys * 4));
+        DevMem d_units, d_uoff, d_hv, d_hv_alt, d_hk, d_hk_alt, d_run, d_rep, d_pkeys, d_pkeys_alt, d_pvals, d_pvals_alt;
         BD_HIP(d_units.alloc((size_t)n_keys * 4));
         BD_HIP(d_uoff.alloc((size_t)n_keys * 4));
-        uint64_t cap = 1024;
-        while (cap < 2ull * n_keys) cap <<= 1;      // list keys <= keys
-        BD_HIP(d_tab_hash.alloc((size_t)cap * 8));
-        BD_HIP(d_tab_rep.alloc((size_t)cap * 4));
-        a.slot_of = d_slot_of.as<uint32_t>();
+        BD_HIP(d_hv.alloc((size_t)n_keys * 8));
+        BD_HIP(d_hv_alt.alloc((size_t)n_keys * 8));
+        BD_HIP(d_hk.alloc((size_t)n_keys * 4));
+        BD_HIP(d_hk_alt.alloc((size_t)n_keys * 4));
+        BD_HIP(d_run.alloc((size_t)n_keys * 4));
+        BD_HIP(d_rep.alloc((size_t)n_keys * 4));
         a.units = d_units.as<uint32_t>();
         a.uoff = d_uoff.as<uint32_t>();
-        a.tab_hash = d_tab_hash.as<uint64_t>();
-        a.tab_rep = d_tab_rep.as<uint32_t>();
-        a.tab_mask = (uint32_t)(cap - 1);
+        a.rep_of = d_rep.as<uint32_t>();
         const unsigned kb = blocks_for(n_keys, 256);
         for (int attempt = 0;; attempt++) {
             a.seed = 0x9E3779B97F4A7C15ull * (uint64_t)(attempt + 1);
             if (getenv("KAAMER_BUILD_WEAK_HASH") && attempt == 0) a.seed = 0;  // tests: forces the collision path
             BD_HIP(hipMemset(st, 0, sizeof(BuildStats)));
-            BD_HIP(hipMemset(d_tab_hash.p, 0, (size_t)cap * 8));
-            BD_HIP(hipMemset(d_tab_rep.p, 0xFF, (size_t)cap * 4));
+            a.hv = d_hv.as<uint64_t>();
+            a.hk = d_hk.as<uint32_t>();
             hipLaunchKernelGGL(bd_hash_kernel, dim3(kb), dim3(256), 0, 0, a);
+            {
+                rocprim::double_buffer<uint64_t> hb(d_hv.as<uint64_t>(), d_hv_alt.as<uint64_t>());
+                rocprim::double_buffer<uint32_t> kb3(d_hk.as<uint32_t>(), d_hk_alt.as<uint32_t>());
+                size_t need = 0;
+                BD_HIP(rocprim::radix_sort_pairs(nullptr, need, hb, kb3, (size_t)n_keys, 0u, 64u));
+                if (need > tmp_bytes) { BD_HIP(d_tmp.alloc(need)); tmp_bytes = need; }
+                BD_HIP(rocprim::radix_sort_pairs(d_tmp.p, need, hb, kb3, (size_t)n_keys, 0u, 64u));
+                a.hv_s = hb.current();
+                a.hk_s = kb3.current();
+                auto heads = rocprim::make_transform_iterator(rocprim::counting_iterator<uint32_t>(0), RunHead{ a.hv_s });
+                need = 0;
+                BD_HIP(rocprim::inclusive_scan(nullptr, need, heads, d_run.as<uint32_t>(), (size_t)n_keys, MaxU32()));
+                if (need > tmp_bytes) { BD_HIP(d_tmp.alloc(need)); tmp_bytes = need; }
+                BD_HIP(rocprim::inclusive_scan(d_tmp.p, need, heads, d_run.as<uint32_t>(), (size_t)n_keys, MaxU32()));
+                a.run_start = d_run.as<uint32_t>();
+            }
+            hipLaunchKernelGGL(bd_rep_kernel, dim3(kb), dim3(256), 0, 0, a);
             hipLaunchKernelGGL(bd_share_kernel, dim3(kb), dim3(256), 0, 0, a);
             BD_HIP(hipMemcpy(&hs, st, sizeof hs, hipMemcpyDeviceToHost));
             if (!hs.collision) {
@@ -538,7 +569,7 @@ int kaamer_build_on_device(const uint8_t *seqs, const uint64_t *offsets, const u
         }
         tr.lap("hash + share", hs.n_lists);
         if (hs.ub_units + 1 >= KH_INLINE_BIT) return kaamer_fail(KAAMER_E_ARG, "arena exceeds 32 GiB per shard");   // builder.cpp's bound
-        d_tab_hash.release();
+        d_hv.release(); d_hv_alt.release(); d_hk.release(); d_hk_alt.release(); d_run.release();
         {
             size_t need = 0;
             BD_HIP(rocprim::exclusive_scan(nullptr, need, a.units, a.uoff, 1u, (size_t)n_keys, rocprim::plus<uint32_t>()));
@@ -561,7 +592,7 @@ int kaamer_build_on_device(const uint8_t *seqs, const uint64_t *offsets, const u
         tr.lap("arena", arena_words);
         // the pairs are not needed any more
         BD_HIP(hipDeviceSynchronize());
-        d_pairs.release(); d_pairs_alt.release(); d_slot_of.release(); d_units.release(); d_uoff.release(); d_tab_rep.release();
+        d_pairs.release(); d_pairs_alt.release(); d_units.release(); d_uoff.release(); d_rep.release();
 
         // ---- placement -------------------------------------------------------------------------------------
         BD_HIP(d_pkeys_alt.alloc((size_t)n_keys * 8));
