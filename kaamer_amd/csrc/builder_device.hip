@@ -212,17 +212,21 @@ __device__ inline bool key_is_inline(const KeyArrays &a, uint32_t k, uint32_t &s
 // the 0.3 s DB-SP build went into those contended atomics; the sort is ~10 ms.)
 __global__ __launch_bounds__(256) void bd_hash_kernel(KeyArrays a)
 {
-    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    // grid-stride: the four statistics below are ONE word each, and an atomic per wave on a single word serialises at
+    // ~90 atomics/us -- with a thread per key and 2 M waves that was 90 ms of this "hash" kernel (rounds 2-3 blamed the
+    // table's atomics); a block now walks many keys and adds its totals once
     unsigned long long n_inline = 0, ub = 0, mx = 0, mpid = 0;
-    if (k < a.n_keys) {
+    for (uint64_t k64 = (uint64_t)blockIdx.x * 256u + threadIdx.x; k64 < a.n_keys; k64 += (uint64_t)gridDim.x * 256u) {
+        const uint32_t k = (uint32_t)k64;
         uint32_t s, c;
         const bool inl = key_is_inline(a, k, s, c);
-        mpid = (uint32_t)a.pairs[s + c - 1];
+        const unsigned long long last = (uint32_t)a.pairs[s + c - 1];
+        mpid = last > mpid ? last : mpid;
         uint64_t h = 0;
-        if (inl) n_inline = 1;
+        if (inl) n_inline++;
         else {
-            ub = (1ull + c + 3ull) / 4ull;
-            mx = c;
+            ub += (1ull + c + 3ull) / 4ull;
+            mx = c > mx ? c : mx;
             h = a.seed ^ c;
             // seed 0 (tests only): the hash is the set's size, so unequal sets meet
             for (uint32_t t = 0; a.seed && t < c; t++) h = bd_mix64(h + (uint32_t)a.pairs[s + t] * 0x9E3779B97F4A7C15ull);
@@ -259,13 +263,13 @@ __global__ __launch_bounds__(256) void bd_rep_kernel(KeyArrays a)
 // pass 2: representatives take arena space; everyone else proves it holds the representative's set
 __global__ __launch_bounds__(256) void bd_share_kernel(KeyArrays a)
 {
-    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
     unsigned long long n_lists = 0;
-    if (k < a.n_keys) {
+    for (uint64_t k64 = (uint64_t)blockIdx.x * 256u + threadIdx.x; k64 < a.n_keys; k64 += (uint64_t)gridDim.x * 256u) {   // (grid-stride: see bd_hash_kernel)
+        const uint32_t k = (uint32_t)k64;
         uint32_t s, c, u = 0;
         if (!key_is_inline(a, k, s, c)) {
             const uint32_t rep = a.rep_of[k];
-            if (rep == k) { u = (1u + c + 3u) / 4u; n_lists = 1; }
+            if (rep == k) { u = (1u + c + 3u) / 4u; n_lists++; }
             else {
                 const uint32_t rs = a.kstart[rep], rc = a.kstart[rep + 1] - rs;
                 bool same = rc == c;
@@ -541,7 +545,7 @@ int kaamer_build_on_device(const uint8_t *seqs, const uint64_t *offsets, const u
             BD_HIP(hipMemset(st, 0, sizeof(BuildStats)));
             a.hv = d_hv.as<uint64_t>();
             a.hk = d_hk.as<uint32_t>();
-            hipLaunchKernelGGL(bd_hash_kernel, dim3(kb), dim3(256), 0, 0, a);
+            hipLaunchKernelGGL(bd_hash_kernel, dim3(kb < 4096u ? kb : 4096u), dim3(256), 0, 0, a);
             {
                 rocprim::double_buffer<uint64_t> hb(d_hv.as<uint64_t>(), d_hv_alt.as<uint64_t>());
                 rocprim::double_buffer<uint32_t> kb3(d_hk.as<uint32_t>(), d_hk_alt.as<uint32_t>());
@@ -559,7 +563,7 @@ int kaamer_build_on_device(const uint8_t *seqs, const uint64_t *offsets, const u
                 a.run_start = d_run.as<uint32_t>();
             }
             hipLaunchKernelGGL(bd_rep_kernel, dim3(kb), dim3(256), 0, 0, a);
-            hipLaunchKernelGGL(bd_share_kernel, dim3(kb), dim3(256), 0, 0, a);
+            hipLaunchKernelGGL(bd_share_kernel, dim3(kb < 4096u ? kb : 4096u), dim3(256), 0, 0, a);
             BD_HIP(hipMemcpy(&hs, st, sizeof hs, hipMemcpyDeviceToHost));
             if (!hs.collision) {
                 if (tr.on) fprintf(stderr, "[kaamer device build] content-hash attempts: %d\n", attempt + 1);

@@ -32,10 +32,20 @@ for i in range(nq):
 cells = sum(len(seqs[a]) * len(seqs[b]) for a, b in pairs)
 packed = api.pack_sequences(seqs)
 api.align_pairs(packed=packed, pairs=pairs[:64], number_of_aa=2e8)        # warm-up
-t0 = time.perf_counter()
+import ctypes as C
+from kaamer_amd import abi
+L = abi.lib()
+buf, offs = np.ascontiguousarray(packed[0]), np.ascontiguousarray(packed[1])
+pq = np.ascontiguousarray([p[0] for p in pairs], dtype=np.uint32)
+ps = np.ascontiguousarray([p[1] for p in pairs], dtype=np.uint32)
+for rep in range(2):
+    h = C.c_void_p()
+    t0 = time.perf_counter()
+    abi.check(L.kaamer_align_pairs(0, buf.ctypes.data, offs.ctypes.data, len(offs) - 1, pq.ctypes.data, ps.ctypes.data, len(pq), int(2e8), b"blosum62", 11, 1, C.byref(h)))
+    dt = time.perf_counter() - t0
+    L.kaamer_alignments_free(h)
+    print("kaamer_align_pairs: %d pairs, %.3e cells in %.3f s = %.1f GCUPS (upload, kernel, traceback, host post-processing)" % (len(pairs), cells, dt, cells / dt / 1e9))
 got = api.align_pairs(packed=packed, pairs=pairs, number_of_aa=2e8)
-dt = time.perf_counter() - t0
-print("device: %d pairs, %.3e cells in %.3f s = %.1f GCUPS (host post-processing and copies included)" % (len(pairs), cells, dt, cells / dt / 1e9))
 sample = pairs[:: max(1, len(pairs) // 200)]
 t0 = time.perf_counter()
 for a, b in sample:
