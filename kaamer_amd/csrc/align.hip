@@ -12,12 +12,18 @@
 // corrected by (gap length - 1) * GapExtend per gap, the +1 on the start coordinates -- follows align.go and
 // matrixScores.go line by line.
 //
-// Device work: one LANE per pair (the pairs of a batch are tens of thousands of independent 350 x 350 problems: a
-// 10 000-query batch with MaxResults 10 is 1.2e10 cells).  A wave takes 64 pairs of similar size (the host sorts them);
-// the three layers of the previous row live in a scratch array interleaved by lane, so that every load and store of
-// the inner loop is one coalesced 256-byte access per wave; one byte per cell (the predecessor layer of each of the
-// three layers) goes to a direction array laid out the same way, and the traceback walks it backwards.  Integer
-// arithmetic only; the host turns the operations into the reference's strings and numbers.
+// Device work (a 10 000-query batch with MaxResults 10 is 100 000 pairs of ~350 x 350 cells = 1.2e10 cells):
+//   align_wave_kernel   one WAVE per pair, the classic anti-diagonal wavefront: the 64 lanes hold 64 consecutive query
+//                       rows, step d computes cell (row, d - lane); the three layers of the cell above come from the
+//                       neighbouring lane's registers (one DPP wave shift each), those of the diagonal are last step's
+//                       "above", those of the left cell the lane's own last results -- no memory traffic for the
+//                       recurrence at all.  Strips of 64 rows hand their last row to the next strip through LDS, the
+//                       subject's letter indices and the 26 x 26 matrix sit in LDS too.  One byte per cell (the
+//                       predecessor layer of each of the three layers) goes to HBM diagonal-major, 64 bytes per step
+//                       and wave, coalesced; lane 0 walks it backwards for the traceback.
+//   align_kernel        one LANE per pair with the rows in HBM: the fallback for subjects longer than the LDS row
+//                       buffer holds (ALN_WAVE_NS letters).
+// Integer arithmetic only; the host turns the operations into the reference's strings and numbers.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -235,6 +241,124 @@ __global__ __launch_bounds__(64) void align_kernel(AlignParams p)
     p.out[w.first_pair + lane] = o;
 }
 
+// ---- one wave per pair: anti-diagonal wavefront ----------------------------------------------------------------------
+#define ALN_WAVE_NS 2048u   /* longest subject the LDS row buffer holds (3 layers x 4 bytes x (ALN_WAVE_NS + 1)) */
+
+struct WPair {
+    uint32_t q_off, nq, s_off, ns;
+    uint64_t dir_off;   // bytes: strips x (ns + 63) steps x 64 lanes
+    uint64_t ops_off;   // bytes: nq + ns
+};
+
+struct WaveParams {
+    const uint8_t *codes;
+    const WPair *pairs;
+    const int *matrix;
+    int gap_open;
+    uint8_t *dirs;
+    uint8_t *ops;
+    PairOut *out;
+    uint32_t first;     // index of pairs[0] in `out`
+};
+
+// value of the next lower lane (lane 0: `first`): DPP wave_shr:1
+__device__ __forceinline__ int from_lower_lane(int v, int first)
+{
+    return __builtin_amdgcn_update_dpp(first, v, 0x138, 0xf, 0xf, false);
+}
+
+__global__ __launch_bounds__(64) void align_wave_kernel(WaveParams p)
+{
+    __shared__ int s_m[NL * NL];
+    __shared__ int s_bnd[3][ALN_WAVE_NS + 1];   // the last row of the previous strip, per layer, by column (0 = zeros)
+    __shared__ uint8_t s_sub[ALN_WAVE_NS];
+    const uint32_t lane = threadIdx.x;
+    const WPair d = p.pairs[blockIdx.x];
+    for (uint32_t i = lane; i < NL * NL; i += 64) s_m[i] = p.matrix[i];
+    for (uint32_t j = lane; j < d.ns; j += 64) s_sub[j] = p.codes[d.s_off + j];
+    for (uint32_t j = lane; j <= d.ns; j += 64) { s_bnd[0][j] = 0; s_bnd[1][j] = 0; s_bnd[2][j] = 0; }
+    __syncthreads();
+    const uint32_t steps = d.ns + 63u;
+    uint8_t *const dir = p.dirs + d.dir_off + lane;
+    int best = 0, best_i = 0, best_j = 0, best_l = 0;
+    uint32_t strip = 0;
+    for (uint32_t i0 = 0; i0 < d.nq; i0 += 64, strip++) {
+        const uint32_t i = i0 + lane + 1;                 // this lane's row (1-based)
+        const bool row_live = i <= d.nq;
+        const int rv = row_live ? (int)p.codes[d.q_off + i - 1] : 0;
+        const int gr = s_m[rv * NL];                      // the gap-column score of the query letter
+        int cm = 0, cu = 0, cl = 0;                       // this lane's last cell (zeros: column 0 / not a cell)
+        int pu_m = 0, pu_u = 0, pu_l = 0;                 // the cell above last step's cell = this step's diagonal
+        uint8_t *const sdir = dir + (uint64_t)strip * steps * 64;
+        for (uint32_t st = 0; st < steps; st++) {
+            const int j = (int)st - (int)lane + 1;        // this step's column (1-based)
+            const bool cell = row_live && j >= 1 && j <= (int)d.ns;
+            // the cell above: the lower lane's last results (its row is i - 1, its last column was j); lane 0 reads the
+            // previous strip's last row
+            const int jc = j < 0 ? 0 : (j > (int)d.ns ? (int)d.ns : j);
+            const int b_m = s_bnd[0][jc], b_u = s_bnd[1][jc], b_l = s_bnd[2][jc];
+            const int up_m = from_lower_lane(cm, b_m), up_u = from_lower_lane(cu, b_u), up_l = from_lower_lane(cl, b_l);
+            const int qv = cell ? (int)s_sub[j - 1] : 0;
+            int v, nm = 0, nu = 0, nl = 0;
+            unsigned k, f = 0;
+            arg3(pu_m, pu_u, pu_l, v, k);                 // diag: the best layer of (i-1, j-1) + the substitution score
+            const int pm = v;
+            v += s_m[rv * NL + qv];
+            if (v > 0) { nm = v; f |= pm > 0 ? k : 0u; }
+            arg3(up_m + p.gap_open + gr, up_u + gr, up_l + p.gap_open + gr, v, k);       // up: consumes the query letter
+            if (v > 0) { nu = v; f |= k << 2; }
+            const int gq = s_m[qv];
+            arg3(cm + p.gap_open + gq, cu + p.gap_open + gq, cl + gq, v, k);             // left: consumes the subject letter
+            if (v > 0) { nl = v; f |= k << 4; }
+            if (!cell) { nm = nu = nl = 0; f = 0; }
+            sdir[(uint64_t)st * 64] = (uint8_t)f;
+            // the first best cell in row-major order: within a row columns ascend, a lane's rows ascend with the strips
+            if (nm > best) { best = nm; best_i = (int)i; best_j = j; best_l = 0; }
+            if (nu > best) { best = nu; best_i = (int)i; best_j = j; best_l = 1; }
+            if (nl > best) { best = nl; best_i = (int)i; best_j = j; best_l = 2; }
+            pu_m = up_m; pu_u = up_u; pu_l = up_l;
+            cm = nm; cu = nu; cl = nl;
+            // the strip's last row feeds the next strip (column j was read by lane 0 sixty-three steps ago)
+            if (lane == 63 && cell) { s_bnd[0][j] = nm; s_bnd[1][j] = nu; s_bnd[2][j] = nl; }
+        }
+        __syncthreads();   // (one wave: orders the LDS row between strips)
+    }
+    // the best cell over the lanes: highest score, then the smallest row
+    unsigned long long key = ((unsigned long long)(uint32_t)best << 32) | (uint32_t)(0x7FFFFFFF - best_i);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long other = __shfl_xor(key, o, 64);
+        key = other > key ? other : key;
+    }
+    const int w_best = (int)(key >> 32), w_i = 0x7FFFFFFF - (int)(uint32_t)key;
+    const unsigned long long mine = __ballot(best == w_best && best_i == w_i && w_best > 0);
+    int max_j = 0, max_l = 0;
+    if (mine) {
+        const int src = __ffsll((long long)mine) - 1;
+        max_j = __shfl(best_j, src, 64);
+        max_l = __shfl(best_l, src, 64);
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (lane != 0) return;
+    // traceback (lane 0): cell (i, j) lives in strip (i-1)/64 at step (j-1) + (i-1)%64, lane (i-1)%64
+    uint8_t *const ops = p.ops + d.ops_off;
+    int i = w_best > 0 ? w_i : 0, j = max_j, l = max_l, n_ops = 0;
+    const int end_i = i, end_j = j;
+    while (i > 0 && j > 0) {
+        const uint32_t ln = (uint32_t)(i - 1) & 63u, sp = (uint32_t)(i - 1) >> 6;
+        const unsigned f = p.dirs[d.dir_off + ((uint64_t)sp * steps + (uint32_t)(j - 1) + ln) * 64 + ln];
+        const unsigned pred = (f >> (2 * l)) & 3u;
+        ops[n_ops++] = l == 0 ? 'M' : l == 1 ? 'U' : 'L';
+        if (l == 0) { i--; j--; } else if (l == 1) i--; else j--;
+        if (pred == 0) break;
+        l = (int)pred - 1;
+    }
+    PairOut o;
+    o.max_s = w_best; o.end_i = end_i; o.end_j = end_j; o.start_i = i; o.start_j = j; o.n_ops = n_ops;
+    p.out[p.first + blockIdx.x] = o;
+}
+
 template <class T> struct DevBuf {
     T *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
@@ -331,10 +455,19 @@ int kaamer_align_pairs(int device, const uint8_t *seqs, const uint64_t *offsets,
         if (nq > 0x3FFFFFFFull || ns > 0x3FFFFFFFull) { res->items[i].status = 3; continue; }
         work.push_back(Work{ i, (uint32_t)nq, (uint32_t)ns });
     }
-    std::sort(work.begin(), work.end(), [](const Work &a, const Work &b) {
+    // the wave-per-pair kernel takes every pair whose subject fits its LDS row buffer; longer subjects go to the lane-per-pair
+    // kernel, sorted by size so that the 64 lanes of a wave walk similar matrices; pairs without a cell need no device
+    uint32_t wave_ns = ALN_WAVE_NS;
+    if (const char *e = getenv("KAAMER_ALIGN_WAVE_NS")) { const long v = atol(e); if (v >= 0 && v <= (long)ALN_WAVE_NS) wave_ns = (uint32_t)v; }
+    auto klass = [&](const Work &w) { return (w.nq == 0 || w.ns == 0) ? 2 : (w.ns <= wave_ns ? 0 : 1); };
+    std::sort(work.begin(), work.end(), [&](const Work &a, const Work &b) {
+        const int ka = klass(a), kb = klass(b);
+        if (ka != kb) return ka < kb;
         const uint64_t ca = (uint64_t)a.nq * a.ns, cb = (uint64_t)b.nq * b.ns;
         return ca != cb ? ca > cb : a.pair < b.pair;
     });
+    size_t n_wave = 0, n_lane = 0;
+    for (const Work &w : work) { if (klass(w) == 0) n_wave++; else if (klass(w) == 1) n_lane++; }
     std::vector<PairDesc> pd(work.size());
     for (size_t i = 0; i < work.size(); i++) {
         const uint32_t q = pair_query[work[i].pair], s = pair_subject[work[i].pair];
@@ -342,13 +475,15 @@ int kaamer_align_pairs(int device, const uint8_t *seqs, const uint64_t *offsets,
     }
     if (total > 0xFFFFFFFFull) { delete res; return kaamer_fail(KAAMER_E_ARG, "align_pairs: more than 4 GiB of sequence"); }
     std::vector<PairOut> po(work.size());
+    memset(po.data(), 0, po.size() * sizeof(PairOut));
     std::vector<std::vector<uint8_t>> ops_of(work.size());
-    if (!work.empty()) {
+    if (n_wave + n_lane) {
         ALN_HIP(hipSetDevice(device));
         uint64_t budget = 4ull << 30;                  // bytes of direction array per launch
         if (const char *e = getenv("KAAMER_ALIGN_DIR_BYTES")) budget = strtoull(e, nullptr, 10);
         DevBuf<uint8_t> d_codes, d_dirs, d_ops;
         DevBuf<PairDesc> d_pairs;
+        DevBuf<WPair> d_wpairs;
         DevBuf<WaveDesc> d_waves;
         DevBuf<int> d_matrix, d_rows;
         DevBuf<PairOut> d_out;
@@ -360,16 +495,52 @@ int kaamer_align_pairs(int device, const uint8_t *seqs, const uint64_t *offsets,
         ALN_HIP(hipMemcpy(d_codes.p, codes.data(), codes.size(), hipMemcpyHostToDevice));
         ALN_HIP(hipMemcpy(d_pairs.p, pd.data(), pd.size() * sizeof(PairDesc), hipMemcpyHostToDevice));
         ALN_HIP(hipMemcpy(d_matrix.p, matrix, sizeof matrix, hipMemcpyHostToDevice));
+        // ---- wave per pair
         size_t at = 0;
-        while (at < pd.size()) {
+        while (at < n_wave) {
+            std::vector<WPair> wp;
+            uint64_t dirs = 0, opsb = 0;
+            size_t end = at;
+            while (end < n_wave) {
+                const PairDesc &x = pd[end];
+                const uint64_t dbytes = (uint64_t)((x.nq + 63) / 64) * (x.ns + 63) * 64;
+                if (!wp.empty() && dirs + dbytes > budget) break;
+                wp.push_back(WPair{ x.q_off, x.nq, x.s_off, x.ns, dirs, opsb });
+                dirs += dbytes;
+                opsb += (uint64_t)x.nq + x.ns;
+                end++;
+            }
+            rc = d_wpairs.alloc(wp.size());
+            if (!rc) rc = d_dirs.alloc((size_t)dirs);
+            if (!rc) rc = d_ops.alloc((size_t)opsb);
+            if (rc) { delete res; return rc; }
+            ALN_HIP(hipMemcpy(d_wpairs.p, wp.data(), wp.size() * sizeof(WPair), hipMemcpyHostToDevice));
+            WaveParams vp;
+            vp.codes = d_codes.p; vp.pairs = d_wpairs.p; vp.matrix = d_matrix.p; vp.gap_open = dp_open;
+            vp.dirs = d_dirs.p; vp.ops = d_ops.p; vp.out = d_out.p; vp.first = (uint32_t)at;
+            hipLaunchKernelGGL(align_wave_kernel, dim3((unsigned)wp.size()), dim3(64), 0, 0, vp);
+            ALN_HIP(hipGetLastError());
+            ALN_HIP(hipDeviceSynchronize());
+            ALN_HIP(hipMemcpy(po.data() + at, d_out.p + at, (end - at) * sizeof(PairOut), hipMemcpyDeviceToHost));
+            std::vector<uint8_t> h_ops((size_t)opsb);
+            if (opsb) ALN_HIP(hipMemcpy(h_ops.data(), d_ops.p, (size_t)opsb, hipMemcpyDeviceToHost));
+            for (size_t t = at; t < end; t++) {
+                const PairOut &o = po[t];
+                ops_of[t].assign(h_ops.begin() + (size_t)wp[t - at].ops_off, h_ops.begin() + (size_t)wp[t - at].ops_off + (size_t)o.n_ops);
+            }
+            at = end;
+        }
+        // ---- lane per pair (subjects beyond the LDS row buffer)
+        const size_t lane_end = n_wave + n_lane;
+        while (at < lane_end) {
             // one launch: waves until the direction array is full (a single wave may exceed the budget: it runs alone)
             std::vector<WaveDesc> waves;
             uint64_t rows = 0, dirs = 0, opsb = 0;
             size_t end = at;
-            while (end < pd.size()) {
+            while (end < lane_end) {
                 WaveDesc w;
                 w.first_pair = (uint32_t)end;
-                w.n_pairs = (uint32_t)std::min<size_t>(64, pd.size() - end);
+                w.n_pairs = (uint32_t)std::min<size_t>(64, lane_end - end);
                 w.max_nq = w.max_ns = 0;
                 for (uint32_t t = 0; t < w.n_pairs; t++) { w.max_nq = std::max(w.max_nq, pd[end + t].nq); w.max_ns = std::max(w.max_ns, pd[end + t].ns); }
                 const uint64_t dbytes = (uint64_t)w.max_nq * w.max_ns * 64;

@@ -109,7 +109,7 @@ def _mutate(rng, s, n_sub, n_indel):
 @pytest.mark.gpu
 def test_device_alignments_equal_the_restatement(klib, oracle, gpu_device, monkeypatch):
     """kaamer_align_pairs against oracle/align_oracle.c on related, unrelated, nested and degenerate pairs: every number and
-    every column of the three rows; more pairs than one wave holds; several launches (a small direction-array budget)"""
+    every column of the three rows; both device kernels; several launches (a small direction-array budget)"""
     from kaamer_amd import api, workload
     rng = np.random.default_rng(17)
     db = workload.unpack(workload.make_db(120, seed=5))
@@ -135,9 +135,14 @@ def test_device_alignments_equal_the_restatement(klib, oracle, gpu_device, monke
     n = len(seqs)
     pairs += [(n - 4, n - 4), (n - 3, n - 2), (n - 2, n - 3), (n - 2, n - 1), (0, 1), (1, 0)]
     n_aa = 2 * 10 ** 8
-    for budget in (None, "200000"):
-        if budget:
-            monkeypatch.setenv("KAAMER_ALIGN_DIR_BYTES", budget)
+    # the wave-per-pair kernel (default), several launches of it, the lane-per-pair kernel alone (the fallback for subjects
+    # beyond the LDS row buffer), and both in one call
+    for budget, wave_ns in ((None, None), ("200000", None), (None, "0"), ("3000000", "100")):
+        for k_, v_ in (("KAAMER_ALIGN_DIR_BYTES", budget), ("KAAMER_ALIGN_WAVE_NS", wave_ns)):
+            if v_ is None:
+                monkeypatch.delenv(k_, raising=False)
+            else:
+                monkeypatch.setenv(k_, v_)
         got = api.align_pairs(seqs=seqs, pairs=pairs, number_of_aa=n_aa, device=gpu_device)
         n_gaps = 0
         for (qi, si), g in zip(pairs, got):
