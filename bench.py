@@ -199,8 +199,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=0,
                     help="batches in flight: batch i runs on workspace/stream i %% inflight.  Default 3 for protein batches "
                          "(the probe kernel is bound by memory requests, the counting kernel by latency: neighbouring batches "
-                         "overlap, +32 %% throughput), 1 for nucleotide batches (their kernels fill the device: no gain) and "
-                         "in sharded mode")
+                         "overlap, +32 %% throughput) and for 1 M-read batches (+8-12 %%), 4 on the skewed database, 1 in sharded mode")
     ap.add_argument("--compact", type=int, default=0,
                     help="1: finish every batch with the hit lists packed in query order (one more scan + copy pass); "
                          "0 (default): each query's list stays where the search kernel wrote it (offset + count per query)")
@@ -229,8 +228,9 @@ def main():
     if args.inflight <= 0:
         # batches in flight, each on its own stream and workspace.  The skewed databases gain most: their batches end in
         # a tail of a few monster queries' workgroups, which the next batches' kernels fill (1 / 2 / 3 / 4 / 6 in flight:
-        # 4.28 / 2.32 / 1.67 / 1.42 / 1.78 ms per batch); 1 M-read batches fill the device on their own (6.86 / 6.70 / 6.41)
-        args.inflight = 1 if (nucl or args.mode == "sharded") else (4 if args.db == "zipf" else 3)
+        # 4.28 / 2.32 / 1.67 / 1.42 / 1.78 ms per batch); 1 M-read batches gain 8-12 % (round 4, same box: 7.10 ms with one
+        # in flight, 6.25-6.56 with three: the probe kernel of batch i+1 runs next to the counting kernel of batch i)
+        args.inflight = 1 if args.mode == "sharded" else (4 if args.db == "zipf" else 3)
     if args.db.startswith("zipf"):
         args.g_tier_slots = args.g_tier_slots or (1 << 30)
         args.max_hits = args.max_hits or (1 << 28)
