@@ -279,7 +279,16 @@ def main():
     t0 = time.time()
     # the table is built on the device it is searched on (builder_device.hip; byte-identical to the host builder's image)
     if os.environ.get("KAAMER_EXP_ARENA_ORDER"):   # experiment: the image comes back to the host and is re-laid there at open time
-        ix = api.Index.from_image(api.Image.from_proteins(packed=db, load_factor=args.load_factor, device=local_rank), local_rank)
+        img_ = api.Image.from_proteins(packed=db, load_factor=args.load_factor, device=local_rank)
+        if os.environ["KAAMER_EXP_ARENA_ORDER"] == "2":   # lists in first-touch order of a walk over the proteins' windows
+            t0 = time.time()
+            L_ = abi.lib()
+            L_.kaamer_exp_relayout_first_touch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32]
+            b_, o_ = np.ascontiguousarray(db[0]), np.ascontiguousarray(db[1])
+            abi.check(L_.kaamer_exp_relayout_first_touch(img_._h, b_.ctypes.data, o_.ctypes.data, len(o_) - 1))
+            os.environ["KAAMER_EXP_ARENA_ORDER"] = "0"   # (the open-time hook then only compacts in the order it finds)
+            log("experiment: arena re-laid in first-touch order in %.1fs" % (time.time() - t0))
+        ix = api.Index.from_image(img_, local_rank)
     else:
         ix = api.Index.from_proteins(packed=db, load_factor=args.load_factor, device=local_rank,
                                      shard=rank if sharded_mode else 0, n_shards=world if sharded_mode else 1)

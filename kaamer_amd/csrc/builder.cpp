@@ -458,4 +458,50 @@ uint32_t kaamer_image_get(const kaamer_image *img, uint32_t key, uint32_t *ids, 
     return 0;
 }
 
+// EXPERIMENT (tools/r4_arena_order.sh, not declared in the public header): re-orders the postings lists of `img` by FIRST TOUCH
+// -- the order in which a walk over the proteins (input order) and their windows (ascending position) meets them -- so that
+// the lists behind consecutive windows of a protein sit in consecutive 16-byte units (four list heads per 64-byte sector).
+int kaamer_exp_relayout_first_touch(kaamer_image *img, const uint8_t *seqs, const uint64_t *offsets, uint32_t n_proteins)
+{
+    if (!img || !offsets || (!seqs && n_proteins)) return kaamer_fail(KAAMER_E_ARG, "exp_relayout: bad argument");
+    const uint64_t units = img->hdr.arena_words / 4;
+    std::vector<uint32_t> new_off((size_t)units + 1, 0u);
+    std::vector<uint32_t> out((size_t)img->hdr.arena_words, 0u);
+    uint32_t cur = 1;
+    const uint64_t nb = img->hdr.n_buckets;
+    auto place = [&](uint32_t old) {
+        if (new_off[old]) return;
+        const uint32_t cnt = img->arena[(uint64_t)old * 4], u = (1u + cnt + 3u) / 4u;
+        memcpy(&out[(size_t)cur * 4], &img->arena[(size_t)old * 4], (size_t)u * 16);
+        new_off[old] = cur;
+        cur += u;
+    };
+    for (uint32_t p = 0; p < n_proteins; p++) {
+        const uint8_t *s = seqs + offsets[p];
+        const uint64_t len = offsets[p + 1] - offsets[p];
+        for (uint64_t i = 0; i + KAAMER_KMER_SIZE <= len; i++) {
+            const uint32_t key = kaamer_encode_kmer(s + i);
+            if (img->hdr.n_shards > 1 && kh_shard_of(key, img->hdr.n_shards) != img->hdr.shard) continue;
+            uint64_t b = kh_home_bucket(key, img->hdr.n_shards, nb);
+            for (uint64_t tries = 0; tries < nb; tries++) {
+                const kh_bucket &bk = img->buckets[b];
+                bool done = false, has_empty = false;
+                for (int t = 0; t < KH_SLOTS_PER_BUCKET; t++) {
+                    if (bk.s[t].key == key) { if (!(bk.s[t].val & KH_INLINE_BIT) && bk.s[t].val) place(bk.s[t].val); done = true; break; }
+                    if (bk.s[t].key == KH_EMPTY_KEY) has_empty = true;
+                }
+                if (done || has_empty) break;
+                b = (b + 1 == nb) ? 0 : b + 1;
+            }
+        }
+    }
+    for (uint64_t b = 0; b < nb; b++)   // (lists no window reached: none, every key came from a window; kept for safety)
+        for (int t = 0; t < KH_SLOTS_PER_BUCKET; t++) {
+            kh_slot &sl = img->buckets[b].s[t];
+            if (sl.key != KH_EMPTY_KEY && !(sl.val & KH_INLINE_BIT) && sl.val) { place(sl.val); sl.val = new_off[sl.val]; }
+        }
+    memcpy(img->arena, out.data(), (size_t)img->hdr.arena_words * 4);
+    return KAAMER_OK;
+}
+
 }  // extern "C"

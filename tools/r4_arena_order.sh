@@ -1,7 +1,7 @@
 #!/bin/bash
 # experiment: what locality between the postings lists of one protein family is worth (lists re-ordered at open time)
 set -o pipefail
-for o in 0 1; do
+for o in ${ORDERS:-0 1 2}; do
   for f in 1 3; do
     KAAMER_EXP_ARENA_ORDER=$o python bench.py --steps 8 --warmup 2 --no-cpu-baseline --check 20 --inflight $f > gpurun_out/ao_${o}_$f.json 2> gpurun_out/ao_${o}_$f.log || { tail -5 gpurun_out/ao_${o}_$f.log; exit 1; }
     python - $o $f <<'PY'
