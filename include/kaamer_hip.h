@@ -146,6 +146,11 @@ int kaamer_makedb_tsv(const char *text, uint64_t len, kaamer_proteins **out);
  *   length beyond the sequence) the entry is dropped; the split-build options -offset / -length are not reproduced. */
 int kaamer_makedb_embl(const char *text, uint64_t len, kaamer_proteins **out);
 int kaamer_makedb_gbk(const char *text, uint64_t len, kaamer_proteins **out);
+/* The four readers behind one entry point (format: 0 FASTA, 1 TSV, 2 EMBL, 3 GBK), with the reference's scanner limit on
+ * request: strict_scanner = 1 ends the input at a line of 1 048 576 bytes or more, as bufio.Scanner with a 1 MiB buffer does
+ * (inputFASTA.go:88-89 and the same two lines in the other readers): what was read before the line is processed as if the
+ * file ended there.  strict_scanner = 0 (what the four functions above do) reads lines of any length. */
+int kaamer_makedb_text(const char *text, uint64_t len, int32_t format, int32_t strict_scanner, kaamer_proteins **out);
 uint32_t kaamer_proteins_count(const kaamer_proteins *p);           /* accepted proteins       */
 const uint32_t *kaamer_proteins_ids(const kaamer_proteins *p);      /* their protein ids       */
 const uint8_t *kaamer_proteins_seqs(const kaamer_proteins *p);      /* packed sequences        */

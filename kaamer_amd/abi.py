@@ -137,6 +137,7 @@ SYMBOLS = {
     "kaamer_makedb_tsv": (C.c_int, [C.c_char_p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "kaamer_makedb_embl": (C.c_int, [C.c_char_p, C.c_uint64, C.POINTER(C.c_void_p)]),
     "kaamer_makedb_gbk": (C.c_int, [C.c_char_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "kaamer_makedb_text": (C.c_int, [C.c_char_p, C.c_uint64, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "kaamer_proteins_count": (C.c_uint32, [C.c_void_p]),
     "kaamer_proteins_ids": (C.POINTER(C.c_uint32), [C.c_void_p]),
     "kaamer_proteins_seqs": (C.POINTER(C.c_uint8), [C.c_void_p]),

@@ -40,6 +40,11 @@ struct kaamer_proteins {
 
 namespace {
 
+// kaamer_makedb_text(strict_scanner = 1): the reference's scanners are bufio.Scanner with Buffer(buf, 1 MiB)
+// (inputFASTA.go:88-89, inputTSV.go, inputEMBL.go, inputGBK.go alike): a line of 1 048 576 bytes or more ('\r' included,
+// '\n' not) fills the buffer without a token, Scan() returns false and the reader goes on as if the input had ended there
+thread_local bool g_strict_scanner = false;
+
 struct Lines {
     const char *p, *end;
     bool next(const char *&b, const char *&e)
@@ -48,6 +53,7 @@ struct Lines {
         const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
         b = p;
         e = nl ? nl : end;
+        if (g_strict_scanner && (size_t)(e - b) >= 1024u * 1024u) { p = end; return false; }
         p = nl ? nl + 1 : end;
         if (e > b && e[-1] == '\r') e--;  // bufio.ScanLines drops one trailing '\r'
         return true;
@@ -418,6 +424,16 @@ int makedb_flat(const char *text, uint64_t len, bool gbk, kaamer_proteins **out)
 extern "C" {
 int kaamer_makedb_embl(const char *text, uint64_t len, kaamer_proteins **out) { return makedb_flat(text, len, false, out); }
 int kaamer_makedb_gbk(const char *text, uint64_t len, kaamer_proteins **out) { return makedb_flat(text, len, true, out); }
+
+int kaamer_makedb_text(const char *text, uint64_t len, int32_t format, int32_t strict_scanner, kaamer_proteins **out)
+{
+    if (format < 0 || format > 3) return kaamer_fail(KAAMER_E_ARG, "makedb_text: format is 0 FASTA, 1 TSV, 2 EMBL, 3 GBK");
+    g_strict_scanner = strict_scanner != 0;
+    const int rc = format == 0 ? kaamer_makedb_fasta(text, len, out) : format == 1 ? kaamer_makedb_tsv(text, len, out)
+                 : format == 2 ? kaamer_makedb_embl(text, len, out) : kaamer_makedb_gbk(text, len, out);
+    g_strict_scanner = false;
+    return rc;
+}
 }
 
 extern "C" {

@@ -411,3 +411,33 @@ def test_random_embl_and_gbk_against_the_restatement(klib):
                 assert {k: v for k, v in e["Features"].items() if v != b""} == {k: v for k, v in r[4].items() if v != b""}, text
             n_kept += len(ref)
         assert n_kept > 20, kind
+
+
+def test_strict_scanner_limit_of_the_database_readers(klib):
+    """inputFASTA.go:88-89 (and the same lines of the other readers): bufio.Scanner with a 1 MiB buffer ends the scan at a
+    line of 1 048 576 bytes or more; kaamer_makedb_text(strict_scanner = 1) reproduces it, the default reads on."""
+    import ctypes as C
+
+    def make(text, fmt, strict):
+        h = C.c_void_p()
+        abi.check(klib.kaamer_makedb_text(text, len(text), fmt, strict, C.byref(h)))
+        return api.Proteins(h.value)
+    MAX = 1024 * 1024
+    head = b">a one\nMKTAYIAKQRQISFVK\n>b two\nMKTAYIAKQR"
+    tail = b"\n>c three\nACDEFGHIKLMNPQRS\n>d four\nACDEFGHIKLMNPQRT\n"
+    for n, cut in ((MAX - 1, False), (MAX, True)):
+        text = head + b"\n" + b"K" * n + tail
+        loose, strict = make(text, 0, 0), make(text, 0, 1)
+        same = api.Proteins.from_fasta(text)
+        assert len(loose) == len(same) == 4 and loose.ids.tolist() == same.ids.tolist()
+        if not cut:
+            assert len(strict) == 4 and bytes(strict.packed[0]) == bytes(loose.packed[0])
+        else:   # the scan ends inside record b: a and what b had so far, b as the file's last record
+            assert len(strict) == 2
+            buf, offs = strict.packed
+            assert bytes(buf[int(offs[1]):int(offs[2])]) == b"MKTAYIAKQR"
+    # TSV: rows behind the long line are never seen
+    tsv = b"EntryID\tSequence\np1\tMKTAYIAKQRQISFVK\np2\t" + b"K" * MAX + b"\np3\tACDEFGHIKLMNPQRS\n"
+    assert len(make(tsv, 1, 0)) == 3 and len(make(tsv, 1, 1)) == 1
+    with pytest.raises(abi.KaamerError):
+        make(b">a\nMKTAYIAK\n", 7, 0)
