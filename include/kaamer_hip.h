@@ -171,13 +171,20 @@ int kaamer_image_build_makedb_device(const kaamer_proteins *p, uint32_t shard, u
  * feature i is features[feature_off[i] .. feature_off[i+1]). */
 typedef struct {
     uint32_t found;             /* 0: no protein under this id (entry zeroed) */
-    uint32_t length;            /* Protein.Length                              */
+    uint32_t length;            /* Protein.Length (EMBL: the length the SQ line */
+                                /* declares; what was indexed)                 */
     const char *entry_id;       /* Protein.EntryId, entry_id_len bytes         */
     uint32_t entry_id_len;
     uint32_t n_features;
-    const uint8_t *sequence;    /* Protein.Sequence, length bytes              */
+    const uint8_t *sequence;    /* Protein.Sequence, sequence_len bytes        */
     const char *features;
     const uint64_t *feature_off; /* n_features + 1                             */
+    uint32_t sequence_len;      /* = length, except for an EMBL entry that     */
+                                /* holds more residues than its SQ line        */
+                                /* declares: the reference indexes             */
+                                /* Sequence[:Length] and stores all of it      */
+                                /* (inputEMBL.go:293-312)                      */
+    uint32_t reserved;
 } kaamer_protein_entry;
 /* FetchHitsInformation (search.go:454-470) for n protein ids at once */
 int kaamer_fetch_hits(const kaamer_proteins *p, const uint32_t *ids, uint32_t n, kaamer_protein_entry *out);

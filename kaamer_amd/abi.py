@@ -98,7 +98,8 @@ class BatchTop(C.Structure):
 
 class ProteinEntry(C.Structure):
     _fields_ = [("found", C.c_uint32), ("length", C.c_uint32), ("entry_id", C.c_void_p), ("entry_id_len", C.c_uint32),
-                ("n_features", C.c_uint32), ("sequence", C.c_void_p), ("features", C.c_void_p), ("feature_off", C.POINTER(C.c_uint64))]
+                ("n_features", C.c_uint32), ("sequence", C.c_void_p), ("features", C.c_void_p), ("feature_off", C.POINTER(C.c_uint64)),
+                ("sequence_len", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class Alignment(C.Structure):

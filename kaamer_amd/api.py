@@ -178,7 +178,7 @@ class Proteins:
                 continue
             fo = [e.feature_off[i] for i in range(e.n_features + 1)]
             blob = C.string_at(e.features + fo[0], fo[-1] - fo[0]) if fo[-1] > fo[0] else b""
-            out.append(dict(EntryId=C.string_at(e.entry_id, e.entry_id_len), Sequence=C.string_at(e.sequence, e.length),
+            out.append(dict(EntryId=C.string_at(e.entry_id, e.entry_id_len), Sequence=C.string_at(e.sequence, e.sequence_len),
                             Length=e.length,
                             Features={names[i]: blob[fo[i] - fo[0]:fo[i + 1] - fo[0]] for i in range(e.n_features)}))
         return out

@@ -36,6 +36,10 @@ struct kaamer_proteins {
     std::vector<uint64_t> feature_off;        // n * n_features + 1
     uint64_t n_aa = 0, n_kmers = 0;           // KStats (inputFASTA.go:141-143)
     std::unordered_map<uint32_t, uint32_t> by_id;  // protein id -> record (a later record with the same id wins)
+    // EMBL entries whose SQ line declares fewer residues than the entry holds: the reference indexes Sequence[:Length]
+    // (inputEMBL.go:309-312) but STORES the whole string as Protein.Sequence (:293-305); `seqs` holds what is indexed,
+    // this holds the whole string of those records (rare: real UniProt entries declare what they hold)
+    std::unordered_map<uint32_t, std::string> full_seq;  // record -> Protein.Sequence
 };
 
 namespace {
@@ -243,7 +247,7 @@ struct Skip {};  // where the Go code would panic (a slice past the end of a sho
 std::string from(const std::string &l, size_t a) { if (a > l.size()) throw Skip(); return l.substr(a); }
 
 // processProteinInputEMBL, inputEMBL.go:189-314.  false: the entry contributes nothing
-bool process_embl_entry(const std::string &entry, std::string &entry_id, std::string &seq, std::vector<std::pair<std::string, std::string>> &feat)
+bool process_embl_entry(const std::string &entry, std::string &entry_id, std::string &seq, std::vector<std::pair<std::string, std::string>> &feat, size_t &declared)
 {
     long long length = 0;
     size_t p0 = 0;
@@ -321,7 +325,7 @@ bool process_embl_entry(const std::string &entry, std::string &entry_id, std::st
     }
     if (length < KAAMER_KMER_SIZE) return false;                                      // :293-295: the DECLARED length
     if ((unsigned long long)length > seq.size()) throw Skip();                       // (the k-mer loop :309-312 would slice past the end)
-    seq.resize((size_t)length);                                                       // windows of Sequence[:Length]
+    declared = (size_t)length;                                                        // windows of Sequence[:Length]; the whole string is stored
     return true;
 }
 
@@ -401,11 +405,16 @@ int makedb_flat(const char *text, uint64_t len, bool gbk, kaamer_proteins **out)
                 std::string entry_id, seq;
                 std::vector<std::pair<std::string, std::string>> feat;
                 bool keep = false;
-                try { keep = gbk ? process_gbk_entry(entry, entry_id, seq, feat) : process_embl_entry(entry, entry_id, seq, feat); }
+                size_t declared = std::string::npos;
+                try { keep = gbk ? process_gbk_entry(entry, entry_id, seq, feat) : process_embl_entry(entry, entry_id, seq, feat, declared); }
                 catch (const Skip &) { keep = false; }   // the reference process would have died here: the entry is dropped
                 if (keep) {
                     std::vector<std::string> vals;
                     for (auto &n : r->feature_names) { const std::string *v = find_feat(feat, n.c_str()); vals.push_back(v ? *v : std::string()); }
+                    if (declared != std::string::npos && declared < seq.size()) {   // indexed: Sequence[:Length]; stored: all of it
+                        r->full_seq[(uint32_t)r->ids.size()] = seq;
+                        seq.resize(declared);
+                    }
                     add_protein(r, protein_nb, entry_id, seq, vals);
                 }
                 entry.clear();
@@ -483,6 +492,12 @@ int kaamer_fetch_hits(const kaamer_proteins *p, const uint32_t *ids, uint32_t n,
         o.entry_id = p->entry_ids.data() + p->entry_off[r];
         o.entry_id_len = (uint32_t)(p->entry_off[r + 1] - p->entry_off[r]);
         o.sequence = p->seqs.data() + p->offsets[r];
+        o.sequence_len = o.length;
+        const auto fs = p->full_seq.find(r);
+        if (fs != p->full_seq.end()) {   // Protein.Sequence is the whole string, Protein.Length the declared one (inputEMBL.go:293-305)
+            o.sequence = reinterpret_cast<const uint8_t *>(fs->second.data());
+            o.sequence_len = (uint32_t)fs->second.size();
+        }
         o.n_features = (uint32_t)nf;
         o.features = p->features.data();
         o.feature_off = p->feature_off.data() + (size_t)r * nf;
@@ -498,8 +513,9 @@ int kaamer_proteins_save(const kaamer_proteins *p, const char *path)
     if (!f) return kaamer_fail(KAAMER_E_IO, "cannot open for writing");
     std::string names;
     for (auto &s : p->feature_names) { names += s; names.push_back('\0'); }
-    const uint64_t hdr[8] = { 0x31544F5250524D41ull /* "AMRPROT1" */, p->ids.size(), p->seqs.size(), p->entry_ids.size(), p->feature_names.size(),
-                              p->features.size(), names.size(), p->n_kmers };
+    // "AMRPROT1"; "AMRPROT2" when whole sequences follow (records whose stored Sequence is longer than what is indexed)
+    const uint64_t hdr[8] = { p->full_seq.empty() ? 0x31544F5250524D41ull : 0x32544F5250524D41ull, p->ids.size(), p->seqs.size(), p->entry_ids.size(),
+                              p->feature_names.size(), p->features.size(), names.size(), p->n_kmers };
     bool ok = fwrite(hdr, sizeof hdr, 1, f) == 1;
     auto put = [&](const void *d, size_t bytes) { if (ok && bytes) ok = fwrite(d, 1, bytes, f) == bytes; };
     put(p->ids.data(), p->ids.size() * 4);
@@ -510,6 +526,19 @@ int kaamer_proteins_save(const kaamer_proteins *p, const char *path)
     put(names.data(), names.size());
     put(p->feature_off.data(), p->feature_off.size() * 8);
     put(p->features.data(), p->features.size());
+    if (!p->full_seq.empty()) {
+        std::vector<uint32_t> recs;
+        for (auto &kv : p->full_seq) recs.push_back(kv.first);
+        std::sort(recs.begin(), recs.end());
+        const uint64_t n_full = recs.size();
+        put(&n_full, 8);
+        for (uint32_t rr : recs) {
+            const std::string &fs = p->full_seq.at(rr);
+            const uint64_t rec_len[2] = { rr, fs.size() };
+            put(rec_len, 16);
+            put(fs.data(), fs.size());
+        }
+    }
     ok = (fclose(f) == 0) && ok;
     return ok ? KAAMER_OK : kaamer_fail(KAAMER_E_IO, "short write");
 }
@@ -521,13 +550,14 @@ int kaamer_proteins_load(const char *path, kaamer_proteins **out)
     FILE *f = fopen(path, "rb");
     if (!f) return kaamer_fail(KAAMER_E_IO, "cannot open protein table");
     uint64_t hdr[8];
-    if (fread(hdr, sizeof hdr, 1, f) != 1 || hdr[0] != 0x31544F5250524D41ull) { fclose(f); return kaamer_fail(KAAMER_E_FORMAT, "not a kaamer protein table"); }
+    if (fread(hdr, sizeof hdr, 1, f) != 1 || (hdr[0] != 0x31544F5250524D41ull && hdr[0] != 0x32544F5250524D41ull)) { fclose(f); return kaamer_fail(KAAMER_E_FORMAT, "not a kaamer protein table"); }
+    const bool v2 = hdr[0] == 0x32544F5250524D41ull;
     // sizes must add up to the file before anything is allocated from them
     fseek(f, 0, SEEK_END);
     const unsigned long long size = (unsigned long long)ftell(f);
     const unsigned long long n = hdr[1], nf = hdr[4];
     const unsigned long long want = sizeof hdr + n * 4 + (n + 1) * 8 + hdr[2] + (n + 1) * 8 + hdr[3] + hdr[6] + (n * nf + 1) * 8 + hdr[5];
-    if (n > 0xFFFFFFFFull || nf > 65536 || hdr[2] > size || hdr[3] > size || hdr[5] > size || hdr[6] > size || want != size) {
+    if (n > 0xFFFFFFFFull || nf > 65536 || hdr[2] > size || hdr[3] > size || hdr[5] > size || hdr[6] > size || (v2 ? want + 8 > size : want != size)) {
         fclose(f);
         return kaamer_fail(KAAMER_E_FORMAT, "protein table header does not match the file");
     }
@@ -548,6 +578,22 @@ int kaamer_proteins_load(const char *path, kaamer_proteins **out)
     get(&names[0], names.size());
     get(p->feature_off.data(), p->feature_off.size() * 8);
     get(p->features.data(), p->features.size());
+    if (v2) {   // whole sequences: every length is checked against what is left of the file before it is allocated
+        uint64_t n_full = 0, left = size - want - 8;
+        get(&n_full, 8);
+        for (uint64_t i = 0; ok && i < n_full; i++) {
+            uint64_t rec_len[2] = { 0, 0 };
+            if (left < 16) { ok = false; break; }
+            get(rec_len, 16);
+            left -= 16;
+            if (!ok || rec_len[0] >= n || rec_len[1] > left) { ok = false; break; }
+            std::string fs((size_t)rec_len[1], '\0');
+            get(&fs[0], fs.size());
+            left -= rec_len[1];
+            p->full_seq[(uint32_t)rec_len[0]] = std::move(fs);
+        }
+        if (left != 0) ok = false;
+    }
     fclose(f);
     // offsets must be monotone and end at the array sizes
     auto mono = [](const std::vector<uint64_t> &o, uint64_t end) {

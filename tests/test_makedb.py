@@ -316,6 +316,7 @@ def _check_flat(p, ref, names):
     assert p.feature_names == names
     for e, r in zip(p.fetch_hits([r[0] for r in ref]), ref):
         assert e["EntryId"] == r[1]
+        assert e["Sequence"] == r[3] and e["Length"] == len(r[2])      # Protein.Sequence is the whole string, Length what was indexed
         assert {k: v for k, v in e["Features"].items() if v != b""} == {k: v for k, v in r[4].items() if v != b""}
 
 
@@ -408,6 +409,7 @@ def test_random_embl_and_gbk_against_the_restatement(klib):
             assert have == [(r[0], r[2]) for r in ref], text
             for e, r in zip(p.fetch_hits([r[0] for r in ref]), ref):
                 assert e["EntryId"] == r[1], text
+                assert e["Sequence"] == r[3] and e["Length"] == len(r[2]), text
                 assert {k: v for k, v in e["Features"].items() if v != b""} == {k: v for k, v in r[4].items() if v != b""}, text
             n_kept += len(ref)
         assert n_kept > 20, kind
@@ -441,3 +443,26 @@ def test_strict_scanner_limit_of_the_database_readers(klib):
     assert len(make(tsv, 1, 0)) == 3 and len(make(tsv, 1, 1)) == 1
     with pytest.raises(abi.KaamerError):
         make(b">a\nMKTAYIAK\n", 7, 0)
+
+
+def test_embl_entry_with_more_residues_than_declared_keeps_them(klib, tmp_path):
+    """inputEMBL.go:293-312: the k-mers are those of Sequence[:Length], the stored Protein.Sequence is the whole string
+    (the table used to cut it); the protein-table file carries the whole string too"""
+    text = EMBL.replace(b"SEQUENCE   20 AA;", b"SEQUENCE   12 AA;", 1)
+    assert text != EMBL
+    R = _makedb_ref()
+    ref = R.run_embl(text)
+    cut = [r for r in ref if len(r[3]) > len(r[2])]
+    assert cut, "the fixture must hold an entry that declares fewer residues than it has"
+    p = api.Proteins.from_embl(text)
+    _check_flat(p, ref, R.EMBL_DEF_FTS)
+    f = tmp_path / "prot.kpt"
+    p.save(f)
+    q = api.Proteins.load(f)
+    _check_flat(q, ref, R.EMBL_DEF_FTS)
+    blob = f.read_bytes()
+    for bad in (blob[:-3], blob + b"\0" * 5):
+        g = tmp_path / "bad.kpt"
+        g.write_bytes(bad)
+        with pytest.raises(abi.KaamerError):
+            api.Proteins.load(g)
