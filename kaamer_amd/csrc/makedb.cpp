@@ -19,6 +19,7 @@
 #include "kaamer_internal.h"
 
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <string>
