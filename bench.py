@@ -200,6 +200,10 @@ def main():
                     help="batches in flight: batch i runs on workspace/stream i %% inflight.  Default 3 for protein batches "
                          "(the probe kernel is bound by memory requests, the counting kernel by latency: neighbouring batches "
                          "overlap, +32 %% throughput) and for 1 M-read batches (+8-12 %%), 4 on the skewed database, 1 in sharded mode")
+    ap.add_argument("--probe-streams", type=int, default=0,
+                    help="0 (default): every batch in flight has a stream of its own.  P >= 1: prep + probe of ALL batches go to P "
+                         "streams (round-robin) and the counting stages to --count-streams streams (kaamer_workspace_set_count_stream)")
+    ap.add_argument("--count-streams", type=int, default=2)
     ap.add_argument("--compact", type=int, default=0,
                     help="1: finish every batch with the hit lists packed in query order (one more scan + copy pass); "
                          "0 (default): each query's list stays where the search kernel wrote it (offset + count per query)")
@@ -390,8 +394,17 @@ def main():
         wss, streams = [searcher.ws], [stream]
     else:
         wss = [api.Workspace(ix, max_bytes, args.queries, **ws_kw) for _ in range(args.inflight)]
-        extra_streams = [torch.cuda.Stream() for _ in range(args.inflight - 1)]  # kept alive
-        streams = [stream] + [x.cuda_stream for x in extra_streams]
+        if args.probe_streams > 0:
+            # dedicated roles: the probe kernels of all batches queue on a few probe streams, the counting stages on count streams
+            pst = [torch.cuda.Stream() for _ in range(args.probe_streams)]
+            cst = [torch.cuda.Stream() for _ in range(max(1, args.count_streams))]
+            extra_streams = pst + cst
+            streams = [pst[w % len(pst)].cuda_stream for w in range(args.inflight)]
+            for w, ws_ in enumerate(wss):
+                ws_.set_count_stream(cst[w % len(cst)].cuda_stream)
+        else:
+            extra_streams = [torch.cuda.Stream() for _ in range(args.inflight - 1)]  # kept alive
+            streams = [stream] + [x.cuda_stream for x in extra_streams]
 
         def launch(i):
             b, w = i % n_distinct, i % args.inflight

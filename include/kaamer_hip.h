@@ -350,6 +350,14 @@ void kaamer_workspace_free(kaamer_workspace *ws);
 int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *d_seqs,
                          const uint64_t *d_offsets, uint32_t n_seqs, uint64_t seq_bytes,
                          int32_t seq_type, void *stream, kaamer_device_result *out);
+/* Two-stream form for callers that keep batches in flight: after this call, kaamer_search_device enqueues prep and
+ * probe on ITS `stream` argument and everything behind the probe kernel (counting tiers, finalize; kaamer_topn_device
+ * follows) on `count_stream`, ordered by events inside the library.  With ONE probe stream shared by all batches and the
+ * workspaces' counting stages on one or two count streams, the device always holds one probe kernel (bound by memory
+ * requests) next to the counting kernels of earlier batches (bound by latency) instead of whatever mix independent
+ * streams drift into.  kaamer_workspace_finish and the exchange calls wait for the counting stage wherever it ran.
+ * stream = NULL: back to one stream. */
+int kaamer_workspace_set_count_stream(kaamer_workspace *ws, void *count_stream);
 /* Sharded index (the table split by hash prefix over several devices): every shard
  * searches the whole batch for the keys it owns, the partial hit lists travel to the
  * query's owner (all-to-all, done by the caller), and the owner merges them here:

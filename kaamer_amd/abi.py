@@ -161,6 +161,7 @@ SYMBOLS = {
     "kaamer_batch_free": (None, [C.POINTER(BatchOut)]),
     "kaamer_workspace_create": (C.c_int, [C.c_void_p, C.POINTER(WorkspaceOpts), C.POINTER(C.c_void_p)]),
     "kaamer_workspace_free": (None, [C.c_void_p]),
+    "kaamer_workspace_set_count_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "kaamer_search_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
                                        C.c_uint64, C.c_int32, C.c_void_p, C.POINTER(DeviceResult)]),
     "kaamer_merge_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64,

@@ -682,6 +682,10 @@ class Workspace:
         abi.check(abi.lib().kaamer_topn_device(self._h, C.byref(o), C.c_void_p(stream), C.byref(r)))
         return r
 
+    def set_count_stream(self, stream):
+        """kaamer_workspace_set_count_stream: the counting stage of this workspace's batches runs on `stream` (raw hipStream_t; 0 / None: off)"""
+        abi.check(abi.lib().kaamer_workspace_set_count_stream(self._h, C.c_void_p(stream or 0)))
+
     @property
     def query_capacity(self):
         return int(abi.lib().kaamer_workspace_query_capacity(self._h))

@@ -1431,6 +1431,11 @@ struct kaamer_workspace {
     uint32_t *d_group_first;
     uint32_t *d_n_groups;
     uint32_t groups_cap;
+    // the counting stage on a stream of its own (kaamer_workspace_set_count_stream): the caller's stream then carries
+    // prep + probe only, so that the probe kernel of batch i + 1 starts while batch i is still counting
+    hipStream_t count_stream;
+    hipEvent_t ev_probe, ev_count;
+    bool split_pending;                 // the last search's counting stage is on count_stream: consumers wait for ev_count
     int grp_grid;
     bool sched_identity;                // groups handed out in index order (no longest-first schedule is built)
     // nucleotide / reads input: 6-frame translation products
@@ -1953,6 +1958,27 @@ static void fill_result_hits(const kaamer_workspace *ws, kaamer_device_result *o
     out->d_hit_first_pos = ws->compact ? ws->d_c_fp : ws->d_hit_fp;
 }
 
+// whoever consumes the workspace's last search on `stream` first waits for its counting stage, if that ran elsewhere
+static int ws_join(kaamer_workspace *ws, hipStream_t stream)
+{
+    if (ws->split_pending && ws->count_stream && ws->count_stream != stream) HIPCHK(hipStreamWaitEvent(stream, ws->ev_count, 0));
+    return KAAMER_OK;
+}
+
+int kaamer_workspace_set_count_stream(kaamer_workspace *ws, void *stream)
+{
+    if (!ws) return kaamer_fail(KAAMER_E_ARG, "workspace_set_count_stream: bad argument");
+    HIPCHK(hipSetDevice(ws->device));
+    if (ws->split_pending) HIPCHK(hipEventSynchronize(ws->ev_count));
+    ws->split_pending = false;
+    ws->count_stream = (hipStream_t)stream;
+    if (stream && !ws->ev_probe) {
+        HIPCHK(hipEventCreateWithFlags(&ws->ev_probe, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ws->ev_count, hipEventDisableTiming));
+    }
+    return KAAMER_OK;
+}
+
 int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *d_seqs, const uint64_t *d_offsets,
                          uint32_t n_seqs, uint64_t seq_bytes, int32_t seq_type, void *stream,
                          kaamer_device_result *out)
@@ -1967,6 +1993,11 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     if (seq_bytes > ws->opts.max_seq_bytes) return kaamer_fail(KAAMER_E_CAPACITY, "batch of %llu bytes exceeds workspace max_seq_bytes", (unsigned long long)seq_bytes);
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipSetDevice(ix->device));
+    {   // the previous batch's counting stage may still be reading this workspace on the count stream
+        const int jrc = ws_join(ws, s);
+        if (jrc) return jrc;
+        ws->split_pending = false;
+    }
     // kernel timers: an event record costs a few microseconds of stream idle time, so they are
     // off unless asked for, and can sample every k-th call (kaamer_workspace_set_timing)
     const bool timed = ws->time_every && (ws->call_no++ % ws->time_every) == 0;
@@ -2102,6 +2133,12 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
     if (ws->nucleotide) hipLaunchKernelGGL(probe_kernel<true>, dim3((unsigned)p_blocks), dim3(64 * P_WAVES), 0, s, pp);
     else hipLaunchKernelGGL(probe_kernel<false>, dim3((unsigned)p_blocks), dim3(64 * P_WAVES), 0, s, pp);
     if (timed) HIPCHK(hipEventRecord(ev[2], s));
+    const bool split = ws->count_stream && ws->count_stream != s && !timed;
+    if (split) {   // everything from here on runs on the count stream, behind the probe kernel
+        HIPCHK(hipEventRecord(ws->ev_probe, s));
+        HIPCHK(hipStreamWaitEvent(ws->count_stream, ws->ev_probe, 0));
+        s = ws->count_stream;
+    }
     // ---- kernel C: counting
     CountParams p;
     memset(&p, 0, sizeof p);
@@ -2217,6 +2254,10 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
                            ws->d_status_out, ws->d_pool_cursor, ws->d_slot_scale, ws->slot_scale_cap, ws->slot_scale_margin);
     if (timed) HIPCHK(hipEventRecord(ev[4], s));
     HIPCHK(hipGetLastError());
+    if (split) {
+        HIPCHK(hipEventRecord(ws->ev_count, s));
+        ws->split_pending = true;
+    }
     ws->clean = true;  // everything up to finalize is enqueued
     ws->last_was_merge = false;
     if (timed) ws->n_timed++;
@@ -2359,6 +2400,7 @@ int kaamer_exchange_pack(kaamer_workspace *ws, const kaamer_exchange_layout *L, 
     // (a layout fitted to fewer queries than the batch turns out to have is an overflow like any other: flagged in the
     // block headers by the scan, reported by every owner)
     HIPCHK(hipSetDevice(ws->device));
+    { const int jrc = ws_join(ws, (hipStream_t)stream); if (jrc) return jrc; }
     if (ws->x_dst_cap < (size_t)L->world * L->q_cap) {
         HIPCHK(hipStreamSynchronize((hipStream_t)stream));
         if (ws->d_x_dst_off) (void)hipFree(ws->d_x_dst_off);
@@ -2599,8 +2641,13 @@ int kaamer_topn_device(kaamer_workspace *ws, const kaamer_topn_opts *opts, void 
     p.top_cnt = ws->d_top_cnt; p.top_pid = ws->d_top_pid; p.top_km = ws->d_top_km; p.top_fp = ws->d_top_fp;
     p.trim = ws->d_top_trim; p.start_pos = ws->d_top_start; p.size_out = ws->d_top_size;
     // lanes per query: a protein query has ~190 hits (a wave), an ORF ~15 (16 lanes: four ORFs per wave)
-    if (src->nucleotide) hipLaunchKernelGGL(topn_kernel<16>, dim3(ws->n_cu * 8), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(topn_kernel<64>, dim3(ws->n_cu * 8), dim3(256), 0, (hipStream_t)stream, p);
+    // a search whose counting stage ran on the count stream: the post-steps follow it there (the caller's stream is the probe
+    // stream of the next batches), and consumers keep waiting for ev_count
+    const bool on_count_stream = ws->split_pending && ws->count_stream;
+    hipStream_t ts = on_count_stream ? ws->count_stream : (hipStream_t)stream;
+    if (src->nucleotide) hipLaunchKernelGGL(topn_kernel<16>, dim3(ws->n_cu * 8), dim3(256), 0, ts, p);
+    else hipLaunchKernelGGL(topn_kernel<64>, dim3(ws->n_cu * 8), dim3(256), 0, ts, p);
+    if (on_count_stream) HIPCHK(hipEventRecord(ws->ev_count, ts));
     HIPCHK(hipGetLastError());
     out->max_results = opts->max_results;
     out->d_top_cnt = ws->d_top_cnt;
@@ -2628,6 +2675,7 @@ int kaamer_workspace_finish(kaamer_workspace *ws, void *stream, kaamer_counters 
     if (!ws) return kaamer_fail(KAAMER_E_ARG, "workspace_finish: bad argument");
     HIPCHK(hipSetDevice(ws->device));
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    if (ws->split_pending) HIPCHK(hipEventSynchronize(ws->ev_count));   // (the counting stage ran on the count stream)
     uint32_t status = 0;
     HIPCHK(hipMemcpy(&status, ws->d_status_out, sizeof status, hipMemcpyDeviceToHost));
     kaamer_counters c;
