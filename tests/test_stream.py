@@ -248,3 +248,53 @@ def test_four_callers_after_warm_up_are_not_slower_than_two(klib, gpu_device):
     run(4, 1)                      # every slot allocates here
     t2, t4 = run(2, 4), run(4, 4)
     assert t4 < 2.0 * t2 + 0.005, "per call: 2 callers %.1f ms, 4 callers %.1f ms" % (t2 * 1e3, t4 * 1e3)
+
+
+@pytest.mark.gpu
+def test_counting_stage_on_its_own_stream(klib, oracle, gpu_device):
+    """kaamer_workspace_set_count_stream: prep + probe on the caller's stream, the counting tiers (and the post-steps) on a
+    second one, ordered by events inside the library; several batches in a row on two workspaces that share one probe
+    stream, protein and reads; results against the oracle, and kaamer_workspace_finish waits for the stage wherever it ran"""
+    import torch
+    from kaamer_amd import abi, api, workload
+    db = workload.make_db(1200, seed=9)
+    ix = api.Index.from_image(api.Image.from_proteins(packed=db), gpu_device)
+    oix = oracle.Index.from_proteins(None, packed=db)
+    probe, c1, c2 = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    for kind, make in ((abi.PROTEIN, lambda s: workload.make_protein_queries(db, 120, seed=s)), (abi.READS, lambda s: workload.make_reads(db, 400, seed=s))):
+        batches = [make(30 + i) for i in range(4)]
+        size = max(len(b[0]) for b in batches)
+        wss = [api.Workspace(ix, size, 400, seq_type=kind) for _ in range(2)]
+        wss[0].set_count_stream(c1.cuda_stream)
+        wss[1].set_count_stream(c2.cuda_stream)
+        d = [(torch.from_numpy(b[0]).cuda(), torch.from_numpy(b[1].view(np.int64)).cuda()) for b in batches]
+        torch.cuda.synchronize()
+        for rep in range(2):
+            for i, b in enumerate(batches):
+                w = wss[i % 2]
+                r = w.search_device(d[i][0].data_ptr(), d[i][1].data_ptr(), len(b[1]) - 1, len(b[0]), stream=probe.cuda_stream)
+                if i >= 2:      # the last batch of each workspace is checked; earlier ones are overwritten in flight
+                    top = w.topn_device(0.05, 10, 10, best_start_codon=(kind == abi.READS), stream=probe.cuda_stream)
+                    c = w.finish(probe.cuda_stream)
+                    nq = int(c["n_queries"])
+                    from kaamer_amd.sharded import dev_tensor
+                    off = dev_tensor(r.d_hit_off, nq, torch.int64).cpu().numpy()
+                    cnt = dev_tensor(r.d_hit_cnt, nq, torch.int32).cpu().numpy()
+                    pid = dev_tensor(r.d_hit_pid, int(r.hit_capacity), torch.int32).cpu().numpy().view(np.uint32)
+                    km = dev_tensor(r.d_hit_kmatch, int(r.hit_capacity), torch.int32).cpu().numpy()
+                    seqs = workload.unpack(b)
+                    queries = [o["seq"] for s in seqs for o in oracle.get_orfs(s)] if kind == abi.READS else [s for s in seqs]
+                    assert nq == len(queries)
+                    n = 0
+                    for qi, qs in enumerate(queries):
+                        exp = {}
+                        if kind == abi.READS or oracle.size_in_kmer(qs) >= 7:
+                            p_, k_, _ = oix.search(qs)
+                            exp = dict(zip(p_.tolist(), k_.tolist()))
+                        a = int(off[qi])
+                        assert dict(zip(pid[a:a + int(cnt[qi])].tolist(), km[a:a + int(cnt[qi])].tolist())) == exp, (kind, i, qi)
+                        n += len(exp)
+                    assert n > 100
+        for w in wss:
+            w.set_count_stream(None)
+            w.close()
