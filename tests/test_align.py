@@ -199,18 +199,19 @@ def test_search_then_align_like_query_result_handler(klib, oracle, gpu_device):
 
 @pytest.mark.gpu
 def test_alignment_properties_at_batch_size(klib, gpu_device):
-    """size-independent properties on a batch as large as a real one (20 000 pairs): a sequence against itself aligns end to
-    end with identity 100 and Raw = the sum of its BLOSUM62 diagonal; Raw is symmetric under swapping query and subject; a
-    subject that contains the query as a substring scores the query's self score"""
+    """size-independent properties on a batch as large as a real one (~12 000 pairs): a sequence against itself aligns end to
+    end with identity 100 and Raw = the sum of its BLOSUM62 diagonal (U counted as '*', align.go:54-55); swapping query and
+    subject of a gap-free alignment leaves Raw alone; a subject that contains the query as a substring scores the query's
+    self score.  (Sequences with X are left out: X against X scores -1, a local alignment drops one at an end.)"""
     from kaamer_amd import api, workload
-    db = workload.unpack(workload.make_db(5000, seed=12))
+    db = [s for s in workload.unpack(workload.make_db(5000, seed=12)) if b"X" not in s]
     rng = np.random.default_rng(3)
     seqs = list(db)
     pairs = [(i, i) for i in range(len(db))]
     for i in range(0, len(db) - 1, 2):
         pairs += [(i, i + 1), (i + 1, i)]
     sub = []
-    for i in range(0, 2500):
+    for i in range(0, min(2500, len(db))):
         s = db[i]
         a = int(rng.integers(0, max(1, len(s) // 3)))
         b = int(rng.integers(2 * len(s) // 3, len(s))) + 1
@@ -219,12 +220,13 @@ def test_alignment_properties_at_batch_size(klib, gpu_device):
     pairs += sub
     got = api.align_pairs(seqs=seqs, pairs=pairs, number_of_aa=10 ** 8, device=gpu_device)
     n = len(db)
-    diag = lambda s: sum(int(klib.kaamer_align_matrix_entry(c, c)) for c in s)
+    diag = lambda s: sum(int(klib.kaamer_align_matrix_entry(c, c)) for c in s.replace(b"U", b"*"))
     for i in range(n):
         g = got[i]
         assert g["raw"] == diag(db[i]) and g["length"] == len(db[i]) and g["identity"] == 100.0 and g["gap_openings"] == 0
         assert (g["query_start"], g["query_end"], g["subject_start"], g["subject_end"]) == (1, len(db[i]), 1, len(db[i]))
     for k in range(n, n + 2 * (n // 2), 2):
-        assert got[k]["raw"] == got[k + 1]["raw"]            # the optimal local score does not depend on which sequence is the query
+        if got[k]["gap_openings"] == 0 and got[k + 1]["gap_openings"] == 0:   # (Raw charges gap extensions after the fact: ties may differ)
+            assert got[k]["raw"] == got[k + 1]["raw"]        # the optimal local score does not depend on which sequence is the query
     for (qi, si), g in zip(sub, got[-len(sub):]):
         assert g["raw"] == diag(seqs[qi]) and g["identity"] == 100.0 and g["query_end"] == len(seqs[qi])
