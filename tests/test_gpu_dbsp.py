@@ -117,3 +117,43 @@ def test_dbsp_qmix_streamed(dbsp, oracle):
             n_rep += 1 if k else 0
             qi += 1
     assert qi == len(cnt) == total["n_queries"] and n_rep > 500
+
+
+def test_dbsp_eight_shards_one_handle(dbsp, gpu_device):
+    """configs[3]'s width at BASELINE size: DB-SP cut into EIGHT hash-prefix shards (each built on the device from the
+    proteins), one kaamer_sharded_index over them (all on this one card: the peer copies become device-to-device copies),
+    a 10 000-query batch and a 100 000-read batch -- blocks of megabytes, thousands of owned queries per shard, the
+    adaptive block size in force from the second call -- against the unsharded kaamer_search_batch_top of the same batch
+    (which the tests above hold to the oracle)."""
+    from kaamer_amd import api, workload
+    db, ix, _ = dbsp
+    world = 8
+    shards = [api.Index.from_proteins(packed=db, shard=r, n_shards=world, device=gpu_device) for r in range(world)]
+    assert sum(s.stats()["n_keys"] for s in shards) == ix.stats()["n_keys"]
+    for s in shards:
+        s.close()
+    imgs = [api.Image.from_proteins(packed=db, shard=r, n_shards=world, device=gpu_device) for r in range(world)]
+    sx = api.ShardedIndex.from_images(imgs, [gpu_device] * world)
+    for im in imgs:
+        im.close()
+    for q, kind in ((workload.make_protein_queries(db, 10000, seed=workload.SEED + 5), abi.PROTEIN),
+                    (workload.make_reads(db, 100000, seed=workload.SEED + 6), abi.READS)):
+        ref = ix.search_top(packed=q, seq_type=kind)
+        for rep in range(2):
+            top = sx.search_top(packed=q, seq_type=kind) if rep == 0 else sx.submit_top(packed=q, seq_type=kind).wait()
+            assert top.n_queries == ref.n_queries and top.n_reported == ref.n_reported > 5000
+            assert np.array_equal(top.rep_query, ref.rep_query) and np.array_equal(top.top_off, ref.top_off)
+            assert np.array_equal(top.top_pid, ref.top_pid) and np.array_equal(top.top_kmatch, ref.top_kmatch)
+            assert np.array_equal(top.trim, ref.trim)
+            for f in ("src_seq", "size_in_kmer", "start_position", "end_position", "plus_strand", "aa_len"):
+                assert np.array_equal(top.meta[f], ref.meta[f]), f
+            if kind == abi.READS:
+                assert np.array_equal(top.top_first_pos, ref.top_first_pos) and bytes(top.orf_aa) == bytes(ref.orf_aa)
+            assert top.counters["n_lookup"] == ref.counters["n_lookup"] and top.counters["n_hits"] == ref.counters["n_hits"]
+            info = sx.exchange_info()
+            assert info["adaptive"] == (rep == 1)
+            if rep == 1:
+                words = 3 if kind == abi.READS else 2
+                payload = 4 * (8 + (info["queries"] + world - 1) // world + words * info["need_entries"])
+                assert info["block_bytes"] <= 1.5 * payload, info
+    sx.close()
