@@ -278,6 +278,15 @@ int kaamer_search_batch(kaamer_index *ix, const kaamer_batch_in *in, kaamer_batc
 int kaamer_search_batch_flat(kaamer_index *ix, const uint8_t *seqs, const uint64_t *offsets, uint32_t n_seqs,
                              int32_t seq_type, int32_t want_positions, kaamer_batch_out **out);
 void kaamer_batch_free(kaamer_batch_out *out);
+/* The call in two halves (the worker pool of search_protein.go:58-118 when the full hit lists are wanted -- -pos reads
+ * PositionHits -- without a blocked thread per batch): submit copies the caller's buffers, takes one of the four slots
+ * (blocks while all are busy) and enqueues; wait brings the hit lists to the host, repeating the batch from the copy when a
+ * workspace bound was too small, and gives the slot back.  A ticket is waited for, or discarded, exactly once. */
+typedef struct kaamer_full_ticket kaamer_full_ticket;
+int kaamer_submit_batch_flat(kaamer_index *ix, const uint8_t *seqs, const uint64_t *offsets, uint32_t n_seqs,
+                             int32_t seq_type, int32_t want_positions, kaamer_full_ticket **ticket);
+int kaamer_wait_batch(kaamer_full_ticket *ticket, kaamer_batch_out **out);
+void kaamer_full_ticket_discard(kaamer_full_ticket *ticket);
 
 /* ------------------------------------------------------------------------- */
 /* Device-resident form of the same call: inputs already in HBM, results left  */

@@ -159,6 +159,9 @@ SYMBOLS = {
     "kaamer_index_get_stats": (C.c_int, [C.c_void_p, C.POINTER(ImageStats)]),
     "kaamer_search_batch": (C.c_int, [C.c_void_p, C.POINTER(BatchIn), C.POINTER(C.POINTER(BatchOut))]),
     "kaamer_batch_free": (None, [C.POINTER(BatchOut)]),
+    "kaamer_submit_batch_flat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "kaamer_wait_batch": (C.c_int, [C.c_void_p, C.POINTER(C.POINTER(BatchOut))]),
+    "kaamer_full_ticket_discard": (None, [C.c_void_p]),
     "kaamer_workspace_create": (C.c_int, [C.c_void_p, C.POINTER(WorkspaceOpts), C.POINTER(C.c_void_p)]),
     "kaamer_workspace_free": (None, [C.c_void_p]),
     "kaamer_workspace_set_count_stream": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -387,6 +387,16 @@ class Index:
             abi.check(abi.lib().kaamer_search_batch(self._h, C.byref(bi), C.byref(out)))
         return BatchResult(out)
 
+    def submit(self, seqs=None, packed=None, seq_type=abi.PROTEIN, want_positions=False):
+        """kaamer_submit_batch_flat -> a ticket whose wait() returns the BatchResult (full hit lists)"""
+        buf, offs = packed if packed is not None else pack_sequences(seqs)
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        t = C.c_void_p()
+        abi.check(abi.lib().kaamer_submit_batch_flat(self._h, buf.ctypes.data if len(buf) else None, offs.ctypes.data, len(offs) - 1,
+                                                     seq_type, int(want_positions), C.byref(t)))
+        return FullTicket(t)
+
     def search_top(self, seqs=None, packed=None, seq_type=abi.PROTEIN, min_k_ratio=0.05, min_k_match=10, max_results=10, flat=True):
         """Host-buffer form that returns the reported hits only (kaamer_search_batch_top_flat; flat=False: the struct
         form): sortMapByValue order, SetBestStartCodon for nucleotide/reads, FilterResults -- all on the device."""
@@ -564,6 +574,30 @@ class Replicas:
     def __del__(self):
         try:
             self.close()
+        except Exception:
+            pass
+
+
+class FullTicket:
+    """one full-hit-list batch in flight (kaamer_full_ticket); wait() exactly once, discarded when dropped"""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def wait(self):
+        out = C.POINTER(abi.BatchOut)()
+        h, self._h = self._h, None
+        abi.check(abi.lib().kaamer_wait_batch(h, C.byref(out)))
+        return BatchResult(out)
+
+    def discard(self):
+        h, self._h = self._h, None
+        if h:
+            abi.lib().kaamer_full_ticket_discard(h)
+
+    def __del__(self):
+        try:
+            self.discard()
         except Exception:
             pass
 

@@ -2838,8 +2838,9 @@ static int host_slot_acquire(kaamer_index *ix, HostSlot &h, const kaamer_workspa
     return KAAMER_OK;
 }
 
-static int search_batch_once(kaamer_index *ix, HostSlot &slot, const kaamer_batch_in *in, uint64_t max_hits, uint64_t g_slots,
-                             uint32_t max_queries, kaamer_batch_out **out)
+// host buffers -> device, search enqueued on the slot's stream; nothing is waited for
+static int search_batch_enqueue(kaamer_index *ix, HostSlot &slot, const kaamer_batch_in *in, uint64_t max_hits, uint64_t g_slots,
+                                uint32_t max_queries, kaamer_device_result *dr)
 {
     const uint64_t seq_bytes = in->offsets[in->n_seqs];
     kaamer_workspace_opts o;
@@ -2857,23 +2858,26 @@ static int search_batch_once(kaamer_index *ix, HostSlot &slot, const kaamer_batc
     int rc = host_slot_acquire(ix, slot, o, seq_bytes, in->n_seqs);
     if (rc) return rc;
     if (!slot.stream) HIPCHK(hipStreamCreateWithFlags(&slot.stream, hipStreamNonBlocking));
+    hipStream_t s = slot.stream;
+    hipError_t e = hipSuccess;
+    if (seq_bytes) e = hipMemcpyAsync(slot.d_seqs, in->seqs, (size_t)seq_bytes, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(slot.d_off, in->offsets, ((size_t)in->n_seqs + 1) * 8, hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return kaamer_fail(KAAMER_E_HIP, "H2D: %s", hipGetErrorString(e));
+    return kaamer_search_device(ix, slot.ws, slot.d_seqs, slot.d_off, in->n_seqs, seq_bytes, in->seq_type, s, dr);
+}
+
+// waits for the slot's stream and brings the full hit lists to the host
+static int search_batch_collect(HostSlot &slot, const kaamer_batch_in *in, const kaamer_device_result &dr, kaamer_batch_out **out)
+{
     kaamer_workspace *ws = slot.ws;
-    uint8_t *d_seqs = slot.d_seqs;
-    uint64_t *d_off = slot.d_off;
     batch_out_owner *bo = nullptr;
     hipStream_t s = slot.stream;
-    kaamer_device_result dr;
     kaamer_counters c;
     uint32_t nq = 0;
     uint64_t n_hits = 0, n_words = 0, n_sa = 0;
     unsigned long long n_aa = 0;
     hipError_t e;
-    e = hipMemcpyAsync(d_seqs, in->seqs, (size_t)seq_bytes, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_off, in->offsets, ((size_t)in->n_seqs + 1) * 8, hipMemcpyHostToDevice, s);
-    if (e != hipSuccess) { rc = kaamer_fail(KAAMER_E_HIP, "H2D: %s", hipGetErrorString(e)); goto done; }
-    rc = kaamer_search_device(ix, ws, d_seqs, d_off, in->n_seqs, seq_bytes, in->seq_type, s, &dr);
-    if (rc) goto done;
-    rc = kaamer_workspace_finish(ws, s, &c);
+    int rc = kaamer_workspace_finish(ws, s, &c);
     if (rc) goto done;
     bo = new (std::nothrow) batch_out_owner();
     if (!bo) { rc = kaamer_fail(KAAMER_E_NOMEM, "batch_out"); goto done; }
@@ -2929,6 +2933,115 @@ static int search_batch_once(kaamer_index *ix, HostSlot &slot, const kaamer_batc
 done:
     delete bo;
     return rc;
+}
+
+static int search_batch_once(kaamer_index *ix, HostSlot &slot, const kaamer_batch_in *in, uint64_t max_hits, uint64_t g_slots,
+                             uint32_t max_queries, kaamer_batch_out **out)
+{
+    kaamer_device_result dr;
+    const int rc = search_batch_enqueue(ix, slot, in, max_hits, g_slots, max_queries, &dr);
+    if (rc) return rc;
+    return search_batch_collect(slot, in, dr, out);
+}
+
+// ---- the same call in two halves (the worker pool of search_protein.go:58-118 without a blocked thread per batch when
+// the full hit lists are wanted: -pos, PositionHits).  submit copies the caller's buffers (they are borrowed for the call
+// only), takes a slot, enqueues; wait collects, repeating the batch from the copy when a bound was too small.
+struct kaamer_full_ticket {
+    kaamer_index *ix;
+    HostSlot *slot;
+    std::vector<uint8_t> *seqs;
+    std::vector<uint64_t> *offs;
+    kaamer_batch_in in;
+    kaamer_device_result dr;
+    uint64_t max_hits, g_slots;
+    uint32_t max_queries;
+    int attempt;
+};
+
+static HostSlot *host_slot_take(kaamer_index *ix, int32_t seq_type)
+{
+    HostSlot *slot = nullptr;
+    std::unique_lock<std::mutex> lock(ix->pool_mu);
+    for (;;) {
+        for (HostSlot &h : ix->host)
+            if (!h.busy && (!slot || (h.ws && h.opts.seq_type == seq_type && !(slot->ws && slot->opts.seq_type == seq_type)))) slot = &h;
+        if (slot) break;
+        ix->pool_cv.wait(lock);
+    }
+    slot->busy = true;
+    return slot;
+}
+
+static void host_slot_give(kaamer_index *ix, HostSlot *h)
+{
+    { std::lock_guard<std::mutex> lock(ix->pool_mu); h->busy = false; }
+    ix->pool_cv.notify_all();
+}
+
+int kaamer_submit_batch_flat(kaamer_index *ix, const uint8_t *seqs, const uint64_t *offsets, uint32_t n_seqs, int32_t seq_type,
+                             int32_t want_positions, kaamer_full_ticket **ticket)
+{
+    if (!ix || !ticket || !offsets || (n_seqs && !seqs)) return kaamer_fail(KAAMER_E_ARG, "submit_batch: bad argument");
+    *ticket = nullptr;
+    HIPCHK(hipSetDevice(ix->device));
+    kaamer_full_ticket *t = new (std::nothrow) kaamer_full_ticket();
+    if (!t) return kaamer_fail(KAAMER_E_NOMEM, "ticket");
+    memset(t, 0, sizeof *t);
+    t->ix = ix;
+    t->seqs = new (std::nothrow) std::vector<uint8_t>(seqs, seqs + offsets[n_seqs]);
+    t->offs = new (std::nothrow) std::vector<uint64_t>(offsets, offsets + n_seqs + 1);
+    if (!t->seqs || !t->offs) { delete t->seqs; delete t->offs; delete t; return kaamer_fail(KAAMER_E_NOMEM, "ticket"); }
+    t->in.seqs = t->seqs->data(); t->in.offsets = t->offs->data(); t->in.n_seqs = n_seqs; t->in.seq_type = seq_type;
+    t->in.want_positions = want_positions;
+    t->max_hits = offsets[n_seqs] * 8 + 65536;
+    t->slot = host_slot_take(ix, seq_type);
+    const int rc = search_batch_enqueue(ix, *t->slot, &t->in, t->max_hits, t->g_slots, t->max_queries, &t->dr);
+    if (rc && rc != KAAMER_E_CAPACITY) {
+        if (t->slot->stream) (void)hipStreamSynchronize(t->slot->stream);
+        host_slot_give(ix, t->slot);
+        delete t->seqs; delete t->offs; delete t;
+        return rc;
+    }
+    if (rc) t->attempt = -1;   // (a bound refused on the host already: wait starts with the retry)
+    *ticket = t;
+    return KAAMER_OK;
+}
+
+int kaamer_wait_batch(kaamer_full_ticket *t, kaamer_batch_out **out)
+{
+    if (!t || !out) return kaamer_fail(KAAMER_E_ARG, "wait_batch: bad argument");
+    *out = nullptr;
+    kaamer_index *ix = t->ix;
+    int rc = hipSetDevice(ix->device) == hipSuccess ? KAAMER_OK : kaamer_fail(KAAMER_E_HIP, "hipSetDevice");
+    const bool nucl = t->in.seq_type == KAAMER_NUCLEOTIDE || t->in.seq_type == KAAMER_READS;
+    while (!rc) {
+        rc = t->attempt < 0 ? KAAMER_E_CAPACITY : search_batch_collect(*t->slot, &t->in, t->dr, out);
+        if (t->attempt < 0) t->attempt = 0;
+        if (rc != KAAMER_E_CAPACITY || t->attempt >= 6) break;
+        t->attempt++;
+        t->max_hits *= 4;
+        t->g_slots = t->g_slots ? t->g_slots * 4 : (128ull << 20);
+        if (nucl) {
+            const uint64_t hard = t->in.offsets[t->in.n_seqs] / 10 + (uint64_t)t->in.n_seqs * 6 + 64;
+            t->max_queries = (uint32_t)(hard > 0xFFFFFFF0ull ? 0xFFFFFFF0ull : hard);
+        }
+        rc = search_batch_enqueue(ix, *t->slot, &t->in, t->max_hits, t->g_slots, t->max_queries, &t->dr);
+    }
+    if (rc && t->slot->stream) (void)hipStreamSynchronize(t->slot->stream);
+    host_slot_give(ix, t->slot);
+    delete t->seqs; delete t->offs; delete t;
+    return rc;
+}
+
+void kaamer_full_ticket_discard(kaamer_full_ticket *t)
+{
+    if (!t) return;
+    (void)hipSetDevice(t->ix->device);
+    if (t->slot->stream) (void)hipStreamSynchronize(t->slot->stream);
+    if (t->slot->ws) t->slot->ws->clean = false;
+    host_slot_give(t->ix, t->slot);
+    delete t->seqs; delete t->offs; delete t;
 }
 
 int kaamer_search_batch(kaamer_index *ix, const kaamer_batch_in *in, kaamer_batch_out **out)

@@ -298,3 +298,36 @@ def test_counting_stage_on_its_own_stream(klib, oracle, gpu_device):
         for w in wss:
             w.set_count_stream(None)
             w.close()
+
+
+@pytest.mark.gpu
+def test_full_hit_lists_in_two_halves(klib, oracle, gpu_device):
+    """kaamer_submit_batch_flat / kaamer_wait_batch: the full-hit-list call (what -pos needs: PositionHits) with several
+    batches in flight from one thread, more tickets than slots over time, a discarded ticket; every result equals the
+    blocking call's, bitmaps included, and a sample the oracle's"""
+    from kaamer_amd import abi, api, workload
+    db = workload.make_db(900, seed=19)
+    ix = api.Index.from_image(api.Image.from_proteins(packed=db), gpu_device)
+    oix = oracle.Index.from_proteins(None, packed=db)
+    batches = [(workload.make_protein_queries(db, 80 + 5 * i, seed=50 + i), abi.PROTEIN) for i in range(4)] + \
+              [(workload.make_reads(db, 150, seed=70 + i), abi.READS) for i in range(2)]
+    refs = [ix.search(packed=q, seq_type=k, want_positions=True) for q, k in batches]
+    tickets = [ix.submit(packed=q, seq_type=k, want_positions=True) for q, k in batches[:3]]   # three of the four slots
+    ix.submit(packed=batches[3][0], seq_type=batches[3][1]).discard()
+    got = [t.wait() for t in tickets]
+    got += [ix.submit(packed=q, seq_type=k, want_positions=True).wait() for q, k in batches[3:]]
+    for r, g in zip(refs, got):
+        assert g.n_queries == r.n_queries
+        for i in range(r.n_queries):
+            assert g.hits(i) == r.hits(i) and g.first_pos(i) == r.first_pos(i)
+        for i in range(0, r.n_queries, 7):
+            assert g.positions(i).keys() == r.positions(i).keys()
+            for p_ in g.positions(i):
+                assert np.array_equal(g.positions(i)[p_], r.positions(i)[p_])
+    seqs = workload.unpack(batches[0][0])
+    for i in range(0, len(seqs), 9):
+        exp = {}
+        if oracle.size_in_kmer(seqs[i]) >= 7:
+            p_, k_, _ = oix.search(seqs[i])
+            exp = dict(zip(p_.tolist(), k_.tolist()))
+        assert got[0].hits(i) == exp
