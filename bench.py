@@ -318,8 +318,8 @@ def main():
     max_bytes = max(len(q[0]) for q in batches)
     if args.db == "ur-lite" and not args.max_hits:
         # a dense database: most k-mers meet several proteins by chance, the counting tables grow with that (the library
-        # scales them from the previous batch's hits per k-mer, up to what the hit arrays were provisioned for)
-        args.max_hits = int(2.0 * int(args.queries * (125 if nucl else 365) * (0.065 + 2.18 * float(int(db[1][-1])) / 1e9) * 1.3))
+        # scales them from the previous batch's hits per k-mer, as far as the batch's positions leave room in the hit arrays)
+        args.max_hits = int(2.5 * int(args.queries * (125 if nucl else 365) * (0.065 + 2.18 * float(int(db[1][-1])) / 1e9) * 1.3))
     ws_kw = dict(seq_type=seq_type, max_hits=args.max_hits or ((64 << 20) if nucl else 0), g_tier_slots=args.g_tier_slots,
                  compact=bool(args.compact), concurrent_batches=args.inflight)
     stream = torch.cuda.current_stream().cuda_stream
@@ -338,7 +338,7 @@ def main():
 
     def shard_hits():   # hit-list capacity of a rank's search workspace (0: the library's default)
         if args.db == "ur-lite":
-            return int(2.0 * partial_entries()) // world + (1 << 20)
+            return int(2.5 * partial_entries()) // world + (1 << 20)
         return max(64 << 20, partial_entries() // world + (1 << 20)) if nucl else 0
 
     def exchange_report(searcher, tstream, bufs, offs, sizes, n_pass=6, final_batch=None):

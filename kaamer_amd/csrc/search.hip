@@ -129,7 +129,10 @@ enum { SLOT_QUEUE_HEAD = N_LISTS, SLOT_STATUS = N_LISTS + 1, SLOT_GROUP_QUEUE = 
        SLOT_N_LONG = N_LISTS + 4, SLOT_TILES_DONE = N_LISTS + 5, SLOT_TR_TICKET = N_LISTS + 6,
        SLOT_QUEUE_SUB = N_LISTS + 7 /* 8 words */, SLOT_G_TICKET = N_LISTS + 15, SLOT_PACK_TICKETS = N_LISTS + 16 /* 64 words */,
        SLOT_G_HITS16 = N_LISTS + 80 /* hits the G tier found, in sixteens (saturating) */,
-       N_SMALL_SLOTS = N_LISTS + 16 + 64 + 1 };
+       SLOT_G_MON_HITS16 = N_LISTS + 81 /* those of its monsters (G_MONSTER_HITS) */, SLOT_G_MONSTERS = N_LISTS + 82 /* how many monsters */,
+       N_SMALL_SLOTS = N_LISTS + 16 + 64 + 3 };
+// a query with more distinct hits than this fits no LDS table at any scale: it says nothing about the tables of the others
+#define G_MONSTER_HITS (GRP_MAX_TABLE / 4u * 3u)
 static_assert(N_SMALL_SLOTS <= 256, "the finalize step zeroes one slot per thread");
 // one entry: everything a tier needs to start on a query, in one 16-byte load
 struct alignas(16) WorkItem {
@@ -769,24 +772,33 @@ __device__ __forceinline__ void finalize_body(unsigned long long *replicas, kaam
         for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
         if (lane == 0) ((unsigned long long *)out)[c] = s;
     }
-    unsigned long long g_hits = 0;
+    unsigned long long g_hits = 0, g_mon_hits = 0, g_monsters = 0;
     if (threadIdx.x == 0) {
         *status_out = IN_FLIGHT ? __hip_atomic_load(&small_state[SLOT_STATUS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : small_state[SLOT_STATUS];
         g_hits = 16ull * (IN_FLIGHT ? __hip_atomic_load(&small_state[SLOT_G_HITS16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : small_state[SLOT_G_HITS16]);
+        g_mon_hits = 16ull * (IN_FLIGHT ? __hip_atomic_load(&small_state[SLOT_G_MON_HITS16], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : small_state[SLOT_G_MON_HITS16]);
+        g_monsters = IN_FLIGHT ? __hip_atomic_load(&small_state[SLOT_G_MONSTERS], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : small_state[SLOT_G_MONSTERS];
     }
     __syncthreads();
     if (threadIdx.x < N_SMALL_SLOTS) small_state[threadIdx.x] = 0;
     if (threadIdx.x < 3) cursors[threadIdx.x * CURSOR_STRIDE] = 0;  // G-tier tail cursor, G arena cursors (count, positions)
-    // the next batch's counting tables: 1.5 x SizeInKmer x (distinct proteins per k-mer of THIS batch, + 20 %), never
-    // below 1.5 x SizeInKmer, never more than the hit arrays were provisioned for (scale_cap, from the workspace's sizes)
+    // the next batch's counting tables: 1.5 x SizeInKmer x (distinct proteins per k-mer of THIS batch x the margin), never
+    // below 1.5 x SizeInKmer, never above scale_cap (8); the prep kernel of the next batch cuts it to what that batch's
+    // positions leave room for in the hit arrays (fit_table_scale)
     if (slot_scale && threadIdx.x == 0) {
-        // (written by this workgroup, above).  Queries that left their LDS table are left out on both sides: a few
-        // monsters with tens of thousands of hits (a skewed database) say nothing about the tables of the others
-        // -- unless most queries went there: then they ARE the typical ones, and everything counts
+        // (written by this workgroup, above).  Queries that left their LDS table are left out on both sides: on a skewed
+        // database a few monsters with tens of thousands of hits say nothing about the tables of the others, and tables
+        // 1.3 x larger for everybody cost the group kernel more than the few G-tier queries they save (measured: + 13 %
+        // per batch on --db zipf).  Unless MANY queries left a table that a larger one would have held (more than an
+        // eighth of the batch, the monsters -- more distinct hits than the largest LDS table holds -- not counted): reads
+        // whose one coding frame finds all the hits, a dense database at scale 1.  Then only the monsters are left out
         const unsigned long long nq = out->n_queries;
-        const bool typical = 2ull * out->n_overflow > nq;
-        const unsigned long long ovf = typical ? 0ull : (out->n_overflow < nq ? out->n_overflow : nq);
-        const unsigned long long hits = typical ? out->n_hits : (out->n_hits > g_hits ? out->n_hits - g_hits : 0ull);
+        const unsigned long long n_ovf = out->n_overflow < nq ? out->n_overflow : nq;
+        const unsigned long long n_mon = g_monsters < n_ovf ? g_monsters : n_ovf;
+        const bool widen = 8ull * (n_ovf - n_mon) > nq;
+        const unsigned long long ovf = widen ? n_mon : n_ovf;
+        const unsigned long long left_out = widen ? g_mon_hits : g_hits;
+        const unsigned long long hits = out->n_hits > left_out ? out->n_hits - left_out : 0ull;
         const unsigned long long lookups = nq ? out->n_lookup / nq * (nq - ovf) + out->n_lookup % nq * (nq - ovf) / nq : 0ull;
         if (lookups) {
             unsigned long long t = (hits * margin_q4 + lookups - 1ull) / lookups;   // sixteenths: 16 x hits / lookups x margin / 16
@@ -818,7 +830,8 @@ __global__ __launch_bounds__(64 * G_WAVES, G_MIN_BLOCKS) void count_global_kerne
     // items (all but one when there are none) leave at once -- they take no part in the completion count either
     const uint32_t n_part = n_items < gridDim.x ? (n_items ? n_items : 1u) : gridDim.x;
     if (blockIdx.x >= n_part) return;
-    unsigned long long tot_hits = 0, f_post = 0, f_lists = 0, f_lids = 0;
+    unsigned long long tot_hits = 0, f_post = 0, f_lists = 0, f_lids = 0, mon_hits = 0;
+    uint32_t mon_q = 0;
     PostCtr pc;
     NullTable nt;
     nt.nd = &s_nd;
@@ -1060,7 +1073,10 @@ __global__ __launch_bounds__(64 * G_WAVES, G_MIN_BLOCKS) void count_global_kerne
             __syncthreads();
             if (q_done) {
                 const unsigned long long base = give_up ? ~0ull : s_base;
-                if (wv == 0 && base != ~0ull) tot_hits += written;
+                if (wv == 0 && base != ~0ull) {
+                    tot_hits += written;
+                    if (written > G_MONSTER_HITS) { mon_hits += written; mon_q++; }
+                }
                 if (tid == 0) { p.q_cnt[q] = (base != ~0ull) ? written : 0u; p.hit_off[q] = (base == ~0ull || written == 0) ? 0 : base; }
                 __syncthreads();
                 continue;
@@ -1141,7 +1157,10 @@ __global__ __launch_bounds__(64 * G_WAVES, G_MIN_BLOCKS) void count_global_kerne
                     }
                 }
             }
-            if (wv == 0) tot_hits += total;
+            if (wv == 0) {
+                tot_hits += total;
+                if (total > G_MONSTER_HITS) { mon_hits += total; mon_q++; }
+            }
         }
         if (tid == 0) { p.q_cnt[q] = (base != ~0ull) ? total : 0u; p.hit_off[q] = base == ~0ull ? 0 : base; }
         __syncthreads();
@@ -1149,8 +1168,13 @@ __global__ __launch_bounds__(64 * G_WAVES, G_MIN_BLOCKS) void count_global_kerne
     if (lane == 0) {
         const uint32_t rep = blockIdx.x * WAVES + wv;
         add_counter(p.counters, rep, CTR_HITS, tot_hits);
-        // (what the queries that left their LDS tables found: the next batch's table scale is worked out without them)
+        // (what the queries that left their LDS tables found, and the monsters among them: finalize_body works the next
+        // batch's table scale out without the ones or the others)
         if (tot_hits) atomicAdd(p.queue_head + (SLOT_G_HITS16 - SLOT_QUEUE_HEAD), (uint32_t)((tot_hits + 15ull) >> 4 > 0x0FFFFFFFull ? 0x0FFFFFFFull : (tot_hits + 15ull) >> 4));
+        if (mon_q) {
+            atomicAdd(p.queue_head + (SLOT_G_MON_HITS16 - SLOT_QUEUE_HEAD), (uint32_t)((mon_hits + 15ull) >> 4 > 0x0FFFFFFFull ? 0x0FFFFFFFull : (mon_hits + 15ull) >> 4));
+            atomicAdd(p.queue_head + (SLOT_G_MONSTERS - SLOT_QUEUE_HEAD), mon_q);
+        }
         add_counter(p.counters, rep, CTR_POST, f_post);
         add_counter(p.counters, rep, CTR_LISTS, f_lists);
         add_counter(p.counters, rep, CTR_LIST_IDS, f_lids);
@@ -1458,7 +1482,8 @@ struct kaamer_workspace {
     uint64_t *d_group_start;            // layout_kernel: slot at which the group's first table starts
     unsigned long long *d_lay_total;    // total table slots of the batch
     uint32_t *d_slot_scale;             // table capacity scale of the next batch, sixteenths (finalize_body)
-    uint32_t slot_scale_cap;            // the largest scale the hit arrays were provisioned for
+    uint32_t slot_scale_cap;            // ceiling of the scale (8: beyond it the tables leave the pack kernel's arena)
+    unsigned long long table_room;      // slots of the hit arrays a batch's tables may take (the G tier's lists come after them)
     uint32_t slot_scale_margin;         // sixteenths: tables of (hits per k-mer) x this
     bool dense_tables;                  // the last finished batch left a table scale of 2 or more: ORF packs take the larger arena
     uint32_t *d_n_sched;
@@ -1862,21 +1887,22 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     if (!rc) {
         const uint32_t one = SLOT_SCALE_ONE;
         if (hipMemcpy(ws->d_slot_scale, &one, 4, hipMemcpyHostToDevice) != hipSuccess) rc = kaamer_fail(KAAMER_E_HIP, "workspace init");
-        // tables of a batch as large as the workspace allows, at scale s (sixteenths): 1.5 x s/16 x positions + 64 per
-        // query; they may take 70 % of the hit arrays (the G tier's lists come after them)
-        const double room = 0.7 * (double)ws->sparse_cap - 64.0 * (double)ws->q_cap;
-        double cap = room > 0 ? room * 16.0 / (1.5 * (double)(ws->pos_cap ? ws->pos_cap : 1)) : 16.0;
-        if (getenv("KAAMER_SLOT_SCALE_MAX")) cap = atof(getenv("KAAMER_SLOT_SCALE_MAX")) * 16.0;
+        // the tables of a batch may take 70 % of the hit arrays (the G tier's lists come after them).  How far a batch's
+        // tables scale inside that room is settled per batch on the device, from the batch's own positions
+        // (fit_table_scale): a workspace sized for 2 amino acids per nucleotide holds ORFs of 0.5 per nucleotide at 4 x
+        ws->table_room = (unsigned long long)(0.7 * (double)ws->sparse_cap);
+        double cap = 128.0;
         // (never above 8: at 3e9 residues on one device, 6.6 hits per k-mer, tables of 12 x 1.5 x SizeInKmer leave the pack
         // kernel's arena and the batch takes 92 ms instead of 44; profiles/r03_dense_database.md)
+        if (getenv("KAAMER_SLOT_SCALE_MAX")) cap = atof(getenv("KAAMER_SLOT_SCALE_MAX")) * 16.0;
         ws->slot_scale_cap = cap < 16.0 ? 16u : cap > 128.0 ? 128u : (uint32_t)cap;
         ws->slot_scale_margin = 30u;   // x 1.9: the hits of a query spread around the batch's mean (measured on DB-UR-lite: 1.2 -> 22.8 ms per
                                        // batch, 1.5 -> 13.9, 1.9 -> 11.9; profiles/r03_dense_database.md)
         ws->dense_tables = getenv("KAAMER_PACK_LONG") != nullptr;
         if (getenv("KAAMER_SLOT_MARGIN")) ws->slot_scale_margin = (uint32_t)(atof(getenv("KAAMER_SLOT_MARGIN")) * 16.0);
         if (getenv("KAAMER_WS_TRACE"))
-            fprintf(stderr, "[kaamer workspace] pos_cap %llu q_cap %u hit_cap %llu sparse_cap %llu slot_scale_cap %u/16\n", (unsigned long long)ws->pos_cap,
-                    ws->q_cap, (unsigned long long)ws->hit_cap, (unsigned long long)ws->sparse_cap, ws->slot_scale_cap);
+            fprintf(stderr, "[kaamer workspace] pos_cap %llu q_cap %u hit_cap %llu sparse_cap %llu table_room %llu slot_scale_cap %u/16\n", (unsigned long long)ws->pos_cap,
+                    ws->q_cap, (unsigned long long)ws->hit_cap, (unsigned long long)ws->sparse_cap, ws->table_room, ws->slot_scale_cap);
     }
     if (!rc) rc = dev_alloc(&ws->d_n_sched, 1);
     if (!rc) rc = dev_alloc(&ws->d_n_groups, 1);
@@ -2046,6 +2072,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         pl.no_sched = (ws->use_group && !ws->sched_identity) ? 0u : 1u;
         pl.d_total = ws->d_lay_total;
         pl.slot_scale = ws->d_slot_scale;
+        pl.room_slots = ws->table_room;
         const uint32_t tiles = (uint32_t)(((uint64_t)n_seqs + 1 + PL_TILE - 1) / PL_TILE);
         hipLaunchKernelGGL(prep_layout_schedule_kernel, dim3(tiles), dim3(LAY_THREADS), 0, s, pl);
     } else {
@@ -2105,7 +2132,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         hipLaunchKernelGGL(orf_order_long_kernel, dim3((unsigned)(n_long_bound < (uint64_t)ws->n_cu * 32 ? (n_long_bound + 3) / 4 + 1 : (uint64_t)ws->n_cu * 8)), dim3(256), 0, s,
                            ws->d_tmp_meta, tp.off_orf, ws->d_long_seq, tp.n_long, ws->d_q, ws->d_nq);
         hipLaunchKernelGGL(prep_orf_kernel, dim3(ws->n_cu * 4), dim3(pb), 0, s, ws->d_q, ws->d_nq, ws->d_valid, ws->d_n_pos,
-                           ws->d_qinfo, ws->d_slots, ws->d_hit_off, ws->d_q_cnt, ws->d_slot_scale);
+                           ws->d_qinfo, ws->d_slots, ws->d_hit_off, ws->d_q_cnt, ws->d_slot_scale, ws->table_room);
         residues = ws->d_orf_aa;
         pos_bound = ws->aa_cap;
         nq_bound = ws->q_cap;
