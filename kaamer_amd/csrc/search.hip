@@ -736,6 +736,7 @@ __device__ __forceinline__ void mark_invalid_range(unsigned long long *invalid, 
 }
 
 #include "count_group.hip.inc"
+#include "count_async.hip.inc"
 #define PK_ARENA_PROT 1600u
 #ifndef PK_ARENA_ORF
 #define PK_ARENA_ORF 640u
@@ -1439,6 +1440,7 @@ struct kaamer_workspace {
     uint32_t *d_c_pid, *d_c_km, *d_c_fp;
     int g_grid, p_grid, n_cu, pack_grid, pack_grid_long;
     bool use_group;
+    bool count_async;                   // protein batches are counted by count_async_kernel (default) instead of count_group_kernel<., 0>
     uint32_t pack_shift;                // log2 of the pack window (slots) of a search: 8 for protein, 10 for ORF batches
     // device buffers
     kaamer_query_meta *d_q;
@@ -1543,8 +1545,13 @@ template <class T> static int dev_alloc(T **p, size_t n)
     return KAAMER_OK;
 }
 
-static void launch_group(const CountParams &p, int grid, bool firstpos, hipStream_t s)
+static void launch_group(const CountParams &p, int grid, bool firstpos, hipStream_t s, bool async)
 {
+    if (async) {   // the barrier-free form (count_async.hip.inc); KAAMER_COUNT_ASYNC=0: the round-3 kernel
+        if (firstpos) hipLaunchKernelGGL((count_async_kernel<true>), dim3(grid), dim3(64 * GRP_WAVES), 0, s, p);
+        else hipLaunchKernelGGL((count_async_kernel<false>), dim3(grid), dim3(64 * GRP_WAVES), 0, s, p);
+        return;
+    }
     if (firstpos) hipLaunchKernelGGL((count_group_kernel<true, 0>), dim3(grid), dim3(64 * GRP_WAVES), 0, s, p);
     else hipLaunchKernelGGL((count_group_kernel<false, 0>), dim3(grid), dim3(64 * GRP_WAVES), 0, s, p);
 }
@@ -1771,9 +1778,19 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     // the reference fills PositionHits only for nucleotide/reads input or with -pos (search.go:416)
     ws->firstpos = opts->first_pos == 1 || (opts->first_pos == 0 && (opts->seq_type == KAAMER_NUCLEOTIDE || opts->seq_type == KAAMER_READS));
     int grp_per_cu = 0, p_per_cu = 0;
-    hipError_t oe = ws->firstpos
-        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&grp_per_cu, count_group_kernel<true, 0>, 64 * GRP_WAVES, 0)
-        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&grp_per_cu, count_group_kernel<false, 0>, 64 * GRP_WAVES, 0);
+    // Which counting kernel takes protein batches.  With batches of other workspaces next to this one (ONE counting
+    // workgroup per CU, below) the barrier-free kernel: its eight waves are all a CU has of this batch, and every wave that
+    // waits at a barrier is a hole in the CU's memory pipeline (same box, A/B/A/B: 0.1290-0.1308 against 0.1343-0.1344 ms per
+    // batch).  Alone on the device, three workgroups per CU, the round-3 kernel: the other workgroups fill one's barrier
+    // waits and the job counters only cost (95 against 115 us).  KAAMER_COUNT_ASYNC=0/1 forces either (the parity tests
+    // run both).
+    ws->count_async = opts->concurrent_batches > 1;
+    if (const char *e = getenv("KAAMER_COUNT_ASYNC")) ws->count_async = atoi(e) != 0;
+    hipError_t oe = ws->count_async
+        ? (ws->firstpos ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&grp_per_cu, count_async_kernel<true>, 64 * GRP_WAVES, 0)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&grp_per_cu, count_async_kernel<false>, 64 * GRP_WAVES, 0))
+        : (ws->firstpos ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&grp_per_cu, count_group_kernel<true, 0>, 64 * GRP_WAVES, 0)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&grp_per_cu, count_group_kernel<false, 0>, 64 * GRP_WAVES, 0));
     if (oe == hipSuccess)
         oe = ws->nucleotide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&p_per_cu, probe_kernel<true>, 64 * P_WAVES, 0)
                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&p_per_cu, probe_kernel<false>, 64 * P_WAVES, 0);
@@ -2208,7 +2225,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         if (ws->use_group) {
             uint64_t gg = ((uint64_t)GRP_MIN_TABLE * nq_bound + 3 * pos_bound) / GRP_BUDGET + 1;
             if (gg > (uint64_t)ws->grp_grid) gg = ws->grp_grid;
-            launch_group(pc, (int)gg, ws->firstpos, s);
+            launch_group(pc, (int)gg, ws->firstpos, s, ws->count_async);
         } else if (ws->nucleotide) {
             // reads of ~150 nt: ORFs of <= 50 residues, tables of 64-128 slots -> the small arena (20 waves per CU);
             // longer sequences (mixed read lengths, contigs): the arena that holds tables of up to 576 slots, or 66 000

@@ -341,3 +341,50 @@ def test_counting_tables_follow_the_previous_batch(klib, oracle, gpu_device):
     plain = api.Workspace(ix, len(buf), len(seqs), first_pos=1)
     ovf_p = [run(plain) for _ in range(2)]
     assert ovf_p[0] == ovf[0] and ovf_p[1] <= ovf_p[0]
+
+
+@pytest.mark.parametrize("first_pos", [1, -1])
+def test_both_counting_kernels(small, klib, oracle, gpu_device, first_pos):
+    """A workspace that says other batches run next to its own (`concurrent_batches` > 1) counts protein batches with
+    the barrier-free kernel (count_async.hip.inc: window, stripe and build jobs from LDS counters, two groups alive per
+    workgroup), one that runs alone with count_group_kernel: same hit lists, first positions and counters from both,
+    equal to the oracle's -- on a ragged batch of many groups per workgroup, with empty and too-short queries, queries
+    that leave their table for the G tier, and tables as large as the arena allows."""
+    from kaamer_amd import api, workload
+    db, img, ix, oix = small
+    rng = np.random.default_rng(11)
+    recs = workload.unpack(db)
+    seqs = workload.unpack(workload.make_protein_queries(db, 700, seed=5))
+    seqs += [b"", b"ACDEFG", recs[3][:7], recs[5] * 9, b"".join(recs[int(i)] for i in rng.integers(0, len(recs), 12))]
+    seqs += [recs[int(i)][: int(n)] for i, n in zip(rng.integers(0, len(recs), 300), rng.integers(1, 60, 300))]
+    seqs += workload.unpack(workload.make_protein_queries(db, 500, seed=6))
+    exp = _oracle_hits(oix, oracle, seqs)
+    ref_c = None
+    for cb in (0, 3):
+        hits, first, c = _device_search(ix, seqs, first_pos=first_pos, concurrent_batches=cb)
+        for i, (h, f) in enumerate(exp):
+            assert hits[i] == h, (cb, i)
+            if first_pos == 1:
+                assert first[i] == f, (cb, i)
+        assert c["n_queries"] == sum(oracle.size_in_kmer(s) >= 7 for s in seqs) and c["n_hits"] == sum(len(h) for h, _ in exp)
+        assert c["n_post"] == sum(sum(h.values()) for h, _ in exp)
+        if ref_c is None:
+            ref_c = c
+        else:
+            assert {k: v for k, v in c.items() if k != "n_overflow"} == {k: v for k, v in ref_c.items() if k != "n_overflow"}
+    # a skewed family: 9 000 proteins behind one motif (tables that fill up, the G tier's three stages) through both kernels
+    alpha = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
+    core = bytes(alpha[rng.integers(0, 20, 40)])
+    fam = [bytes(alpha[rng.integers(0, 20, 8)]) + core[(i % 5):] + bytes(alpha[rng.integers(0, 20, 8)]) for i in range(9000)]
+    fix = api.Index.from_image(api.Image.from_proteins(fam), gpu_device)
+    foix = oracle.Index.from_proteins(fam)
+    fq = [core, bytes(alpha[rng.integers(0, 20, 300)]) + core + bytes(alpha[rng.integers(0, 20, 400)]), fam[7], core[:20]] * 6
+    fq += [bytes(alpha[rng.integers(0, 20, int(n))]) for n in rng.integers(20, 900, 200)]
+    fexp = _oracle_hits(foix, oracle, fq)
+    for cb in (0, 3):
+        hits, first, c = _device_search(fix, fq, first_pos=first_pos, concurrent_batches=cb)
+        for i, (h, f) in enumerate(fexp):
+            assert hits[i] == h, (cb, i)
+            if first_pos == 1:
+                assert first[i] == f, (cb, i)
+        assert c["n_overflow"] >= 12
