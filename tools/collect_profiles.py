@@ -51,7 +51,7 @@ def short(k):
 
 
 os.makedirs(DST, exist_ok=True)
-for f in ("bench_default_n1", "bench_under_rocprof", "bench_inflight1_under_rocprof", "bench_reads_n1", "bench_reads_under_rocprof", "bench_zipf", "bench_zipf_inflight1", "bench_reads_inflight3",
+for f in ("bench_default_n1", "bench_under_rocprof", "bench_inflight1_under_rocprof", "bench_reads_n1", "bench_reads_under_rocprof", "bench_reads_inflight1_under_rocprof", "bench_zipf", "bench_zipf_inflight1", "bench_reads_inflight3",
           "bench_zipf_mid", "bench_mix", "bench_sharded_w1", "bench_sharded_reads_w1", "bench_sharded_default_w1", "bench_post_hostapi", "bench_reads_post_hostapi"):
     if os.path.exists(os.path.join(SRC, f + ".json")):
         shutil.copy(os.path.join(SRC, f + ".json"), os.path.join(DST, "%s_%s.json" % (R, f)))
@@ -59,7 +59,7 @@ for f in ("random_read_bench.txt", "bucket_read_bench.txt", "sq_protein.txt", "s
     if os.path.exists(os.path.join(SRC, f)):
         shutil.copy(os.path.join(SRC, f), os.path.join(DST, "%s_%s" % (R, f)))
 for d, name in (("stats_protein", "_kernel_stats_protein_config1.csv"), ("stats_protein_if1", "_kernel_stats_protein_config1_one_in_flight.csv"),
-                ("stats_reads", "_kernel_stats_reads_config2.csv"), ("stats_sharded", "_kernel_stats_sharded_w1_protein.csv"),
+                ("stats_reads", "_kernel_stats_reads_config2.csv"), ("stats_reads_if1", "_kernel_stats_reads_config2_one_in_flight.csv"), ("stats_sharded", "_kernel_stats_sharded_w1_protein.csv"),
                 ("stats_sharded_reads", "_kernel_stats_sharded_w1_reads.csv")):
     fs = sorted(glob.glob(os.path.join(SRC, d, "*", "*_kernel_stats.csv")) + glob.glob(os.path.join(SRC, d, "*_kernel_stats.csv")), key=os.path.getmtime)
     if fs:

@@ -29,6 +29,8 @@ reads)
   echo "== reads (configs[2]) bench + kernel stats + PMC traffic"
   timeout -k 10 600 python3 bench.py --workload reads > $O/bench_reads_n1.json 2> $O/bench_reads_n1.log || exit 1
   timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_reads -- python3 bench.py --workload reads --no-cpu-baseline > $O/bench_reads_under_rocprof.json 2> $O/stats_reads.log || exit 1
+  echo "== one read batch in flight: every kernel alone on the device"
+  timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_reads_if1 -- python3 bench.py --workload reads --no-cpu-baseline --inflight 1 > $O/bench_reads_inflight1_under_rocprof.json 2> $O/stats_reads_if1.log || exit 1
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_reads -- python3 bench.py --workload reads $PMC --batches-per-step 8 > $O/pmc_fetch_reads.json 2> $O/pmc_fetch_reads.log || exit 1
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_reads -- python3 bench.py --workload reads $PMC --batches-per-step 8 > $O/pmc_write_reads.json 2> $O/pmc_write_reads.log || exit 1
   FILTER="translate_reads|probe_kernel|count_pack|topn" BPS=2 bash tools/pmc_sq.sh $R/sq_reads --workload reads > $O/sq_reads.txt 2>&1 || exit 1
