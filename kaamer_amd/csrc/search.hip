@@ -1784,7 +1784,10 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     // batch).  Alone on the device, three workgroups per CU, the round-3 kernel: the other workgroups fill one's barrier
     // waits and the job counters only cost (95 against 115 us).  KAAMER_COUNT_ASYNC=0/1 forces either (the parity tests
     // run both).
-    ws->count_async = opts->concurrent_batches > 1;
+    // (not on a database with postings lists longer than any counting table -- a skewed one: a window behind such a list keeps
+    // its group alive for long, two live groups per workgroup are not enough then and the static deal of the groups hurts:
+    // --db zipf 1.46 against 1.37 ms per batch, profiles/r04_experiments.md)
+    ws->count_async = opts->concurrent_batches > 1 && ix->hdr.max_list <= GRP_MAX_TABLE;
     if (const char *e = getenv("KAAMER_COUNT_ASYNC")) ws->count_async = atoi(e) != 0;
     hipError_t oe = ws->count_async
         ? (ws->firstpos ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&grp_per_cu, count_async_kernel<true>, 64 * GRP_WAVES, 0)
