@@ -2105,6 +2105,11 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         tp.off_orf = ws->d_off3; tp.off_aa = ws->d_off3 + (cap6 + 1); tp.off_sa = ws->d_off3 + 2 * (cap6 + 1);
         tp.tmp_meta = ws->d_tmp_meta; tp.orf_aa = ws->d_orf_aa; tp.starts_alt = ws->d_starts_alt;
         tp.q_cap = ws->q_cap; tp.aa_cap = ws->aa_cap; tp.sa_cap = ws->sa_cap; tp.status = status;
+        // which lane-per-read kernel: the wide one (reads up to 384 nt, 2 waves per SIMD) when the batch's mean length says that
+        // reads beyond 192 nt are common; a batch of 100-150-nt reads is 4 % slower through it (translate.hip.inc)
+        bool wide_reads = seq_bytes > 160ull * (n_seqs ? n_seqs : 1u);
+        if (const char *e = getenv("KAAMER_WIDE_READS")) wide_reads = atoi(e) != 0;
+        tp.ts_max = wide_reads ? TS_MAX_WIDE : TS_MAX;
         int tgrid = ws->n_cu * 8;  // 256-thread blocks, one (sequence, frame, piece) item per wave at a time
         tp.d_n6 = ws->d_n6;
         int sgrid = ws->n_cu * 8;  // lane-per-read kernel: 2-wave blocks, 13 KB (COUNT) / 30 KB (WRITE) of LDS each
@@ -2147,7 +2152,8 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         hipLaunchKernelGGL(translate_kernel<false>, dim3(tgrid), dim3(256), 0, s, tp);
         for (int a = 0; a < 3; a++) scan_u32(ws->d_pcnt3 + a * mpi, ws->d_n_piece_items, piece_bound, ws->d_poff3 + a * (mpi + 1));
         hipLaunchKernelGGL(long_totals_kernel, dim3((unsigned)((n_long_bound * 6 + 255) / 256)), dim3(256), 0, s, tp);
-        hipLaunchKernelGGL(translate_reads_kernel, dim3(sgrid), dim3(64 * TS_WAVES), 0, s, tp);
+        if (wide_reads) hipLaunchKernelGGL(translate_reads_kernel<TS_MAX_WIDE>, dim3(sgrid), dim3(64 * TS_WAVES), 0, s, tp);
+        else hipLaunchKernelGGL(translate_reads_kernel<TS_MAX>, dim3(sgrid), dim3(64 * TS_WAVES), 0, s, tp);
         hipLaunchKernelGGL(translate_kernel<true>, dim3(tgrid), dim3(256), 0, s, tp);
         hipLaunchKernelGGL(orf_order_long_kernel, dim3((unsigned)(n_long_bound < (uint64_t)ws->n_cu * 32 ? (n_long_bound + 3) / 4 + 1 : (uint64_t)ws->n_cu * 8)), dim3(256), 0, s,
                            ws->d_tmp_meta, tp.off_orf, ws->d_long_seq, tp.n_long, ws->d_q, ws->d_nq);

@@ -205,3 +205,39 @@ def test_contig_piece_boundaries(small, oracle):
     res = ix.search(contigs, seq_type=abi.NUCLEOTIDE)
     n = _check_reads(res, contigs, oracle, oix)
     assert n > 1000
+
+
+@pytest.mark.parametrize("wide", ["0", "1"])
+def test_both_lane_per_read_kernels(small, oracle, monkeypatch, wide):
+    """translate_reads_kernel exists for reads of up to 192 nt (64 codons per frame, three ORFs queued per frame) and of
+    up to 384 nt (128 codons: two mask words, six ORFs per frame); the library picks per batch from the mean read length
+    and KAAMER_WIDE_READS forces either.  The same reads through both: lengths around both limits (what is longer goes a
+    wave per frame through translate_kernel), six 21-codon ORFs back to back in one frame on either strand, ORFs that
+    start in the first mask word and end in the second, 128 start codons in a row."""
+    import random
+    from kaamer_amd import workload
+    db, ix, oix = small
+    monkeypatch.setenv("KAAMER_WIDE_READS", wide)
+    rng = random.Random(23)
+
+    def rnd(n, alphabet="ACGT"):
+        return "".join(rng.choice(alphabet) for _ in range(n)).encode()
+
+    def revcomp(s):
+        return s[::-1].translate(bytes.maketrans(b"ACGT", b"TGCA"))
+    reads = [rnd(n) for n in (189, 190, 191, 192, 193, 194, 195, 196, 250, 251, 252, 299, 300, 301, 381, 382, 383, 384, 385, 386, 387, 500)]
+    reads += workload.unpack(workload.make_reads(db, 60, read_len=250, seed=5)) + workload.unpack(workload.make_reads(db, 60, read_len=300, seed=6))
+    reads += workload.unpack(workload.make_reads(db, 40, read_len=384, seed=7)) + workload.unpack(workload.make_reads(db, 40, read_len=150, seed=8))
+    reads += [rnd(rng.randint(180, 400), "ACGTacgtNn") for _ in range(60)]
+    orf21 = b"ATG" + b"GCA" * 19 + b"TAA"
+    six = orf21 * 6
+    reads += [six + b"AC", b"A" + six + b"C", b"AC" + six + b"A", six + b"ACGTAC", revcomp(six + b"AC"), revcomp(b"A" + six + b"C"),
+              revcomp(b"AC" + six + b"A"),
+              b"GCA" * 128, b"GCA" * 127 + b"TA", b"ATG" * 128, revcomp(b"ATG" * 128), b"ATGTTG" * 64,
+              b"TAA" + b"ATG" + b"GCA" * 100 + b"TAG" + b"GTG" + b"GCA" * 20,      # an ORF across the two mask words, a last open one
+              b"GCA" * 50 + b"GCANNA" * 10 + b"GCA" * 40 + b"TGA" + b"AC",          # unknown codons inside an ORF of 120 codons
+              (b"TTG" + b"GCA" * 20 + b"TAG") * 5 + b"CTGGCA" * 9]
+    assert max(len(r) for r in reads[-15:]) <= 384
+    res = ix.search(reads, seq_type=abi.READS)
+    _check_reads(res, reads, oracle, oix)
+    assert sum(len(oracle.get_orfs(r)) >= 6 for r in reads[-15:]) >= 6
