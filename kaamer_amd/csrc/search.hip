@@ -515,9 +515,15 @@ struct RangeScatter {
     uint32_t *cur, *nd;
     uint2 *items;
     uint32_t R;
+    const uint32_t *first;  // first item of every bucket
+    uint32_t cap;           // items a bucket holds (optimistic partition: the same for all; exact sizes: no limit)
+    uint32_t *ovf;          // set when a bucket is full
     __device__ __forceinline__ bool add_n(uint32_t pid, uint32_t pos, uint32_t n, uint32_t &) const
     {
-        items[atomicAdd(&cur[g_range_of(pid, R)], 1u)] = make_uint2(pid, pos | (n << 16));
+        const uint32_t r = g_range_of(pid, R);
+        const uint32_t at = atomicAdd(&cur[r], 1u);
+        if (at - first[r] < cap) items[at] = make_uint2(pid, pos | (n << 16));
+        else *ovf = 1u;
         return true;
     }
     __device__ __forceinline__ bool over_limit() const { return false; }
@@ -822,6 +828,7 @@ __global__ __launch_bounds__(64 * G_WAVES, G_MIN_BLOCKS) void count_global_kerne
     __shared__ uint32_t s_pref[WAVES][NWIN * 64];
     __shared__ unsigned long long s_post, s_off, s_base, s_reserved;
     __shared__ uint32_t s_roff[G_MAX_RANGES], s_rcur[G_MAX_RANGES], s_rtotal;  // buckets of a partitioned query
+    __shared__ uint32_t s_povf;   // a bucket of the optimistic partition was full
     __shared__ LongSink s_long;
     __shared__ uint32_t b_keys[BigLdsTable::CAP], b_val[BigLdsTable::CAP];
 
@@ -963,7 +970,7 @@ __global__ __launch_bounds__(64 * G_WAVES, G_MIN_BLOCKS) void count_global_kerne
                     expand_long(bt);
                 } else {
                     uint32_t nnew = 0;
-                    const uint32_t b0 = s_roff[r], b1 = r + 1u < R ? s_roff[r + 1u] : s_rtotal;
+                    const uint32_t b0 = s_roff[r], b1 = s_rcur[r];   // (the scatter sweep left every cursor at its bucket's end)
                     for (uint32_t i = b0 + tid; i < b1; i += 64 * WAVES) {
                         if (s_fail) break;
                         const uint2 it = items[i];
@@ -1010,48 +1017,64 @@ __global__ __launch_bounds__(64 * G_WAVES, G_MIN_BLOCKS) void count_global_kerne
             int rc1 = count_bucket(1u, 0u, nullptr);
             if (rc1 == 0 || rc1 == 2) q_done = true;
             if (rc1 == 1) {
-                // ---- partition: bucket sizes, offsets, scatter
+                // ---- partition: bucket sizes, offsets, scatter.  The sizes are GUESSED first: the ranges are a hash of the
+                // protein id, so every bucket gets postings / R items give or take a few per cent, and buckets of 5/4 of that
+                // (+ 2 048) spare the sweep that counts them -- one of a monster's three sweeps over hundreds of thousands
+                // of postings.  A bucket that is full after all (a few ids with very many positions in one range) sends the
+                // query through the exact sizes (attempt 1).
                 uint32_t R = (uint32_t)(s_post / 16384ull) + 2u;  // ~3 000 distinct ids per bucket when ids repeat ~6 times
                 if (R > G_MAX_RANGES) R = G_MAX_RANGES;
-                __syncthreads();
-                if (tid < G_MAX_RANGES) s_roff[tid] = 0;
-                if (tid == 0) { s_fail = 0; s_long.n = 0; }
-                __syncthreads();
-                RangeHist rh;
-                rh.cnt = s_roff; rh.nd = &s_nd; rh.R = R;
-                pc.clear();
-                for (int32_t r0 = 0; r0 < size; r0 += 64 * WAVES * NWIN)
-                    count_windows<RangeHist, NWIN, false>(p, vals, size, r0 + 64 * (int32_t)wv, 64 * WAVES, rh, pc, s_pref[wv], &s_long);
-                __syncthreads();
-                expand_long(rh);
-                __syncthreads();
-                if (wv == 0) {  // exclusive prefix of the bucket sizes (R <= 64: one lane each); cursors start at the offsets
-                    const uint32_t v = lane < R ? s_roff[lane] : 0u;
-                    uint32_t inc = v;
+                for (int attempt = 0; attempt < 2 && !q_done; attempt++) {
+                    uint32_t cap_items = 0xFFFFFFFFu;
+                    __syncthreads();
+                    if (tid == 0) { s_fail = 0; s_long.n = 0; s_povf = 0; }
+                    if (attempt == 0) {
+                        const unsigned long long per = s_post / R;
+                        const unsigned long long c = per + per / 4ull + 2048ull;
+                        if (c * R > 0x7FFFFFFFull) continue;   // (workgroup-uniform) too many postings to guess: count them
+                        cap_items = (uint32_t)c;
+                        if (tid < G_MAX_RANGES) { s_roff[tid] = tid * cap_items; s_rcur[tid] = tid * cap_items; }
+                        if (tid == 0) s_rtotal = R * cap_items;
+                        __syncthreads();
+                    } else {
+                        if (tid < G_MAX_RANGES) s_roff[tid] = 0;
+                        __syncthreads();
+                        RangeHist rh;
+                        rh.cnt = s_roff; rh.nd = &s_nd; rh.R = R;
+                        pc.clear();
+                        for (int32_t r0 = 0; r0 < size; r0 += 64 * WAVES * NWIN)
+                            count_windows<RangeHist, NWIN, false>(p, vals, size, r0 + 64 * (int32_t)wv, 64 * WAVES, rh, pc, s_pref[wv], &s_long);
+                        __syncthreads();
+                        expand_long(rh);
+                        __syncthreads();
+                        if (wv == 0) {  // exclusive prefix of the bucket sizes (R <= 64: one lane each); cursors start at the offsets
+                            const uint32_t v = lane < R ? s_roff[lane] : 0u;
+                            uint32_t inc = v;
 #pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) {
-                        const uint32_t t = __shfl_up(inc, o, 64);
-                        if ((int)lane >= o) inc += t;
+                            for (int o = 1; o < 64; o <<= 1) {
+                                const uint32_t t = __shfl_up(inc, o, 64);
+                                if ((int)lane >= o) inc += t;
+                            }
+                            s_roff[lane] = inc - v;
+                            s_rcur[lane] = inc - v;
+                            if (lane == 63) s_rtotal = inc;
+                        }
+                        __syncthreads();
                     }
-                    s_roff[lane] = inc - v;
-                    s_rcur[lane] = inc - v;
-                    if (lane == 63) s_rtotal = inc;
-                }
-                __syncthreads();
-                const uint32_t n_items = s_rtotal;
-                if (tid == 0) {  // 8 bytes per item: half a 16-byte slot of the arena
-                    const unsigned long long need = ((unsigned long long)n_items + 1ull) / 2ull + 1ull;
-                    const unsigned long long off = atomicAdd(p.g_cursor, need);
-                    if (off + need > p.g_slots) { atomicOr(p.status, (uint32_t)ST_G_ARENA_FULL); s_off = ~0ull; }
-                    else s_off = off;
-                    s_long.n = 0;
-                }
-                __syncthreads();
-                if (s_off == ~0ull) { give_up = true; q_done = true; }
-                else {
+                    const uint32_t n_items = s_rtotal;
+                    if (tid == 0) {  // 8 bytes per item: half a 16-byte slot of the arena
+                        const unsigned long long need = ((unsigned long long)n_items + 1ull) / 2ull + 1ull;
+                        const unsigned long long off = atomicAdd(p.g_cursor, need);
+                        if (off + need > p.g_slots) { atomicOr(p.status, (uint32_t)ST_G_ARENA_FULL); s_off = ~0ull; }
+                        else s_off = off;
+                        s_long.n = 0;
+                    }
+                    __syncthreads();
+                    if (s_off == ~0ull) { give_up = true; q_done = true; break; }
                     uint2 *items = reinterpret_cast<uint2 *>(p.g_keys + 4ull * s_off);
                     RangeScatter rsc;
                     rsc.cur = s_rcur; rsc.items = items; rsc.nd = &s_nd; rsc.R = R;
+                    rsc.first = s_roff; rsc.cap = cap_items; rsc.ovf = &s_povf;
                     pc.clear();
                     for (int32_t r0 = 0; r0 < size; r0 += 64 * WAVES * NWIN)
                         count_windows<RangeScatter, NWIN, false>(p, vals, size, r0 + 64 * (int32_t)wv, 64 * WAVES, rsc, pc, s_pref[wv], &s_long);
@@ -1061,6 +1084,7 @@ __global__ __launch_bounds__(64 * G_WAVES, G_MIN_BLOCKS) void count_global_kerne
                     // never hands a region out twice within a launch): after the barrier (which drains vmcnt) the loads
                     // below miss the L1 and find them in the L2
                     __syncthreads();
+                    if (s_povf != 0u) continue;   // (workgroup-uniform: read after a barrier) a guessed bucket was too small
                     bool overflow = false;
                     for (uint32_t r = 0; r < R && !q_done; r++) {
                         const int rc = count_bucket(R, r, items);
@@ -1069,6 +1093,7 @@ __global__ __launch_bounds__(64 * G_WAVES, G_MIN_BLOCKS) void count_global_kerne
                     }
                     if (!overflow) q_done = true;  // else: a bucket with more distinct ids than the table holds -> the table in HBM
                     else { written = 0; }
+                    break;
                 }
             }
             __syncthreads();
