@@ -820,15 +820,20 @@ __device__ __forceinline__ void finalize_body(unsigned long long *replicas, kaam
 #ifndef G_MIN_BLOCKS
 #define G_MIN_BLOCKS 1
 #endif
+#ifndef G_NWIN
+#define G_NWIN 2   /* windows of 64 positions a wave has in flight in the G tier's sweeps */
+#endif
+#ifdef KAAMER_PHASE_CLOCK
+__device__ unsigned long long g_gtier_clock[2048][16];
+#endif
 __global__ __launch_bounds__(64 * G_WAVES, G_MIN_BLOCKS) void count_global_kernel(CountParams p)
 {
     constexpr int WAVES = G_WAVES;
     __shared__ uint32_t s_nd, s_fail, s_cursor;
-    constexpr int NWIN = 2;
+    constexpr int NWIN = G_NWIN;
     __shared__ uint32_t s_pref[WAVES][NWIN * 64];
     __shared__ unsigned long long s_post, s_off, s_base, s_reserved;
     __shared__ uint32_t s_roff[G_MAX_RANGES], s_rcur[G_MAX_RANGES], s_rtotal;  // buckets of a partitioned query
-    __shared__ uint32_t s_povf;   // a bucket of the optimistic partition was full
     __shared__ LongSink s_long;
     __shared__ uint32_t b_keys[BigLdsTable::CAP], b_val[BigLdsTable::CAP];
 
@@ -840,6 +845,10 @@ __global__ __launch_bounds__(64 * G_WAVES, G_MIN_BLOCKS) void count_global_kerne
     if (blockIdx.x >= n_part) return;
     unsigned long long tot_hits = 0, f_post = 0, f_lists = 0, f_lids = 0, mon_hits = 0;
     uint32_t mon_q = 0;
+#ifdef KAAMER_PHASE_CLOCK   /* tools/phase_clock_gtier.py: where the G tier's time goes, per workgroup (thread 0) */
+    unsigned long long gq_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const unsigned long long gq_start = wall_clock64();
+#endif
     PostCtr pc;
     NullTable nt;
     nt.nd = &s_nd;
@@ -926,6 +935,13 @@ __global__ __launch_bounds__(64 * G_WAVES, G_MIN_BLOCKS) void count_global_kerne
         }
         __syncthreads();
         item = s_item;
+#ifdef KAAMER_PHASE_CLOCK
+        unsigned long long gq_t = wall_clock64();
+        const unsigned long long gq_t0 = gq_t;
+#define GQ_LAP(i) { if (tid == 0) { const unsigned long long t_ = wall_clock64(); gq_acc[i] += t_ - gq_t; gq_t = t_; } }
+#else
+#define GQ_LAP(i) { }
+#endif
         // pass 1: exact number of postings (an upper bound of the distinct proteins)
         pc.clear();
         for (int32_t r0 = 0; r0 < size; r0 += 64 * WAVES * NWIN)
@@ -1014,7 +1030,9 @@ __global__ __launch_bounds__(64 * G_WAVES, G_MIN_BLOCKS) void count_global_kerne
                 }
                 return 0;
             };
+            GQ_LAP(0);   // pass 1
             int rc1 = count_bucket(1u, 0u, nullptr);
+            GQ_LAP(1);   // the whole query in the LDS table
             if (rc1 == 0 || rc1 == 2) q_done = true;
             if (rc1 == 1) {
                 // ---- partition: bucket sizes, offsets, scatter.  The sizes are GUESSED first: the ranges are a hash of the
@@ -1027,7 +1045,7 @@ __global__ __launch_bounds__(64 * G_WAVES, G_MIN_BLOCKS) void count_global_kerne
                 for (int attempt = 0; attempt < 2 && !q_done; attempt++) {
                     uint32_t cap_items = 0xFFFFFFFFu;
                     __syncthreads();
-                    if (tid == 0) { s_fail = 0; s_long.n = 0; s_povf = 0; }
+                    if (tid == 0) { s_fail = 0; s_long.n = 0; s_cursor = 0; }   // (s_cursor: "a guessed bucket was full"; count_bucket resets it)
                     if (attempt == 0) {
                         const unsigned long long per = s_post / R;
                         const unsigned long long c = per + per / 4ull + 2048ull;
@@ -1074,7 +1092,7 @@ __global__ __launch_bounds__(64 * G_WAVES, G_MIN_BLOCKS) void count_global_kerne
                     uint2 *items = reinterpret_cast<uint2 *>(p.g_keys + 4ull * s_off);
                     RangeScatter rsc;
                     rsc.cur = s_rcur; rsc.items = items; rsc.nd = &s_nd; rsc.R = R;
-                    rsc.first = s_roff; rsc.cap = cap_items; rsc.ovf = &s_povf;
+                    rsc.first = s_roff; rsc.cap = cap_items; rsc.ovf = &s_cursor;
                     pc.clear();
                     for (int32_t r0 = 0; r0 < size; r0 += 64 * WAVES * NWIN)
                         count_windows<RangeScatter, NWIN, false>(p, vals, size, r0 + 64 * (int32_t)wv, 64 * WAVES, rsc, pc, s_pref[wv], &s_long);
@@ -1084,13 +1102,18 @@ __global__ __launch_bounds__(64 * G_WAVES, G_MIN_BLOCKS) void count_global_kerne
                     // never hands a region out twice within a launch): after the barrier (which drains vmcnt) the loads
                     // below miss the L1 and find them in the L2
                     __syncthreads();
-                    if (s_povf != 0u) continue;   // (workgroup-uniform: read after a barrier) a guessed bucket was too small
+                    GQ_LAP(2);   // partition sweeps
+                    if (s_cursor != 0u) continue;   // (workgroup-uniform: read after a barrier) a guessed bucket was too small
                     bool overflow = false;
                     for (uint32_t r = 0; r < R && !q_done; r++) {
                         const int rc = count_bucket(R, r, items);
                         if (rc == 1) { overflow = true; break; }
                         if (rc == 2) { q_done = true; give_up = true; }
                     }
+                    GQ_LAP(3);   // buckets
+#ifdef KAAMER_PHASE_CLOCK
+                    if (tid == 0) { gq_acc[6] += 1; gq_acc[7] += s_post; }
+#endif
                     if (!overflow) q_done = true;  // else: a bucket with more distinct ids than the table holds -> the table in HBM
                     else { written = 0; }
                     break;
@@ -1105,6 +1128,9 @@ __global__ __launch_bounds__(64 * G_WAVES, G_MIN_BLOCKS) void count_global_kerne
                 }
                 if (tid == 0) { p.q_cnt[q] = (base != ~0ull) ? written : 0u; p.hit_off[q] = (base == ~0ull || written == 0) ? 0 : base; }
                 __syncthreads();
+#ifdef KAAMER_PHASE_CLOCK
+                if (tid == 0) { const unsigned long long d_ = wall_clock64() - gq_t0; gq_acc[5] += 1; if (d_ > gq_acc[8]) { gq_acc[8] = d_; gq_acc[9] = s_post; } }
+#endif
                 continue;
             }
             if (tid == 0) { s_nd = 0; s_fail = 0; s_cursor = 0; s_long.n = 0; }  // (a bucket overflowed: the table in HBM)
@@ -1191,6 +1217,14 @@ __global__ __launch_bounds__(64 * G_WAVES, G_MIN_BLOCKS) void count_global_kerne
         if (tid == 0) { p.q_cnt[q] = (base != ~0ull) ? total : 0u; p.hit_off[q] = base == ~0ull ? 0 : base; }
         __syncthreads();
     }
+#ifdef KAAMER_PHASE_CLOCK
+    if (tid == 0 && blockIdx.x < 2048) {
+        gq_acc[4] = wall_clock64() - gq_start;
+        for (int i = 0; i < 8; i++) g_gtier_clock[blockIdx.x][i] += gq_acc[i];
+        if (gq_acc[8] > g_gtier_clock[blockIdx.x][8]) { g_gtier_clock[blockIdx.x][8] = gq_acc[8]; g_gtier_clock[blockIdx.x][9] = gq_acc[9]; }
+        if (gq_acc[4] > g_gtier_clock[blockIdx.x][10]) g_gtier_clock[blockIdx.x][10] = gq_acc[4];
+    }
+#endif
     if (lane == 0) {
         const uint32_t rep = blockIdx.x * WAVES + wv;
         add_counter(p.counters, rep, CTR_HITS, tot_hits);
@@ -1598,6 +1632,16 @@ int kaamer_abi_version(void) { return KAAMER_ABI_VERSION; }
 
 #ifdef KAAMER_PHASE_CLOCK
 // measurement build only: the phase clocks of count_group_kernel<., 0> since the last reset
+// per-workgroup clocks of count_global_kernel: out[b * 16 + i]
+int kaamer_debug_gtier_clock(unsigned long long *out, int reset)
+{
+    HIPCHK(hipDeviceSynchronize());
+    static unsigned long long all[2048][16];
+    HIPCHK(hipMemcpyFromSymbol(all, HIP_SYMBOL(g_gtier_clock), sizeof all));
+    memcpy(out, all, sizeof all);
+    if (reset) { memset(all, 0, sizeof all); HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_gtier_clock), all, sizeof all)); }
+    return KAAMER_OK;
+}
 int kaamer_debug_phase_clock(unsigned long long out[16], int reset)
 {
     HIPCHK(hipDeviceSynchronize());
