@@ -234,7 +234,9 @@ def main():
         # a tail of a few monster queries' workgroups, which the next batches' kernels fill (1 / 2 / 3 / 4 / 6 in flight:
         # 4.28 / 2.32 / 1.67 / 1.42 / 1.78 ms per batch); 1 M-read batches gain 8-12 % (round 4, same box: 7.10 ms with one
         # in flight, 6.25-6.56 with three: the probe kernel of batch i+1 runs next to the counting kernel of batch i)
-        args.inflight = 1 if args.mode == "sharded" else (4 if args.db == "zipf" else 3)
+        # (sharded mode: three sharded steps in flight -- the exchange of one batch travels while the next is searched and the
+        # one before is merged; world 1 with the exchange forced: 0.386 / 0.29 / 0.243 ms per protein batch with 1 / 2 / 3)
+        args.inflight = 3 if args.mode == "sharded" else (4 if args.db == "zipf" else 3)
     if args.db.startswith("zipf"):
         args.g_tier_slots = args.g_tier_slots or (1 << 30)
         args.max_hits = args.max_hits or (1 << 28)
@@ -380,16 +382,16 @@ def main():
 
     if sharded_mode:
         from kaamer_amd import sharded
-        tstream = torch.cuda.current_stream()
-        searcher = sharded.ShardedSearcher(ix, rank, world, max_bytes, args.queries, seq_type=seq_type,
-                                           max_entries_per_peer=exchange_entries(), max_hits=shard_hits(),
-                                           transport=args.transport, direct_at_world1=not args.exchange_at_w1)
+        pipe = sharded.ShardedPipeline(max(1, args.inflight), ix, rank, world, max_bytes, args.queries, seq_type=seq_type,
+                                       max_entries_per_peer=exchange_entries(), max_hits=shard_hits(),
+                                       transport=args.transport, direct_at_world1=not args.exchange_at_w1)
+        searcher, tstream = pipe.searchers[0], pipe.streams[0]
 
         def launch(i):
             b = i % n_distinct
-            r = searcher.step(d_bufs[b].data_ptr(), d_offs[b].data_ptr(), args.queries, len(batches[b][0]), tstream)
+            k, r = pipe.step(d_bufs[b].data_ptr(), d_offs[b].data_ptr(), args.queries, len(batches[b][0]))
             if args.post:
-                searcher.topn(tstream)
+                pipe.searchers[k].topn(pipe.streams[k])
             return r
         wss, streams = [searcher.ws], [stream]
     else:
@@ -416,7 +418,7 @@ def main():
     def finish_all():
         c = None
         if sharded_mode:
-            return searcher.finish(tstream)[0]
+            return pipe.finish()[pipe.last_k][0]
         for w_, s_ in zip(wss, streams):
             c = w_.finish(s_)   # also validates the batch (capacity / overflow)
         return c
@@ -426,7 +428,7 @@ def main():
     for b in range(n_distinct):
         if sharded_mode:
             launch(b)
-            per_batch.append(searcher.finish(tstream)[0])
+            per_batch.append(pipe.finish()[pipe.last_k][0])
         else:
             wss[0].search_device(d_bufs[b].data_ptr(), d_offs[b].data_ptr(), args.queries, len(batches[b][0]), stream=streams[0])
             per_batch.append(wss[0].finish(streams[0]))
@@ -465,7 +467,7 @@ def main():
         if not (sharded_mode and e.code == abi.E_CAPACITY and searcher.adaptive):
             raise
         log("a batch outgrew its adaptive exchange blocks: timing again with capacity-sized blocks")
-        searcher.adaptive = False
+        pipe.set_adaptive(False)
         launch(n_launch); n_launch += 1
         finish_all()
         elapsed, first_timed, last = timed_region()
@@ -517,25 +519,29 @@ def main():
         cbuf = [torch.from_numpy(q[0]).cuda() for q in cb]
         coff = [torch.from_numpy(q[1].view(np.int64)).cuda() for q in cb]
         sizes = [len(q[0]) for q in cb]
-        ts = torch.cuda.current_stream()
-        ss = sharded.ShardedSearcher(six, rank, world, max(sizes), args.queries, seq_type=seq_type,
+        # three sharded steps in flight (searchers, streams and communicators of their own): a batch's blocks travel while
+        # the next batch is searched and the one before is merged
+        sp = sharded.ShardedPipeline(3, six, rank, world, max(sizes), args.queries, seq_type=seq_type,
                                      max_entries_per_peer=exchange_entries(), max_hits=shard_hits(),
                                      transport=args.transport)
+        ss, ts = sp.searchers[0], sp.streams[0]
         lookups = []
-        for b in range(2):
-            ss.step(cbuf[b].data_ptr(), coff[b].data_ptr(), args.queries, sizes[b], ts, topn={})
-            lookups.append(ss.finish(ts)[0]["n_lookup"])
+        for b in range(6):   # (each searcher sees both batches: its block layout follows ITS earlier batches)
+            sp.step(cbuf[b % 2].data_ptr(), coff[b % 2].data_ptr(), args.queries, sizes[b % 2], topn={})
+            c_ = sp.finish()[sp.last_k]
+            if b < 2:
+                lookups.append(c_[0]["n_lookup"])
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for i in range(n_batches):
-            ss.step(cbuf[i % 2].data_ptr(), coff[i % 2].data_ptr(), args.queries, sizes[i % 2], ts, topn={})
+            sp.step(cbuf[i % 2].data_ptr(), coff[i % 2].data_ptr(), args.queries, sizes[i % 2], topn={})
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         dt = time.perf_counter() - t1
-        ss.finish(ts)
+        sp.finish()
         tt = torch.tensor([dt, float(sum(lookups[i % 2] for i in range(n_batches)))], dtype=torch.float64, device="cuda")
         if world > 1:
             dist.all_reduce(tt[:1], op=dist.ReduceOp.MAX)
@@ -543,10 +549,11 @@ def main():
         rep, _ = exchange_report(ss, ts, cbuf, coff, sizes)
         rep.update({"ms_per_batch": float(tt[0]) / n_batches * 1e3, "lookups_per_s": float(tt[1]) / float(tt[0]),
                     "query_seqs_per_s": args.queries * n_batches / float(tt[0]), "batches": n_batches, "scaling": "strong",
+                    "steps_in_flight": len(sp),
                     "shard_build_s_rank0": build_s, "shard_keys_rank0": sst["n_keys"],
                     "workload": "one common batch of %d %s searched by all %d ranks, each against its hash-prefix shard"
                                 % (args.queries, "reads" if nucl else "protein queries", world)})
-        ss.close()
+        sp.close()
         six.close()
         return rep
 

@@ -106,7 +106,7 @@ class ShardedSearcher:
 
     def __init__(self, index, rank, world, max_seq_bytes, max_seqs, seq_type=abi.PROTEIN, max_entries_per_peer=1 << 20,
                  group=None, max_hits=0, g_tier_slots=0, first_pos=None, transport="torch", comm=None, adaptive=True,
-                 margin=0.25, direct_at_world1=False):
+                 margin=0.25, direct_at_world1=False, concurrent_batches=0):
         """first_pos: carry the lowest matching position of every hit through the exchange.  Default: as the reference
         fills PositionHits (search.go:416) -- nucleotide / reads input yes (SetBestStartCodon reads it), protein input no
         (a third less to pack, send, unpack and merge).
@@ -116,7 +116,9 @@ class ShardedSearcher:
         same on every rank (kaamer_exchange_stats).  A batch that does not fit raises KaamerError(E_CAPACITY) from
         finish() on every rank; `run()` repeats it at full capacity.
         direct_at_world1: with ONE shard the partial lists ARE the results -- skip pack, exchange and merge (the second
-        counting pass) and run the post-steps on the search workspace."""
+        counting pass) and run the post-steps on the search workspace.
+        concurrent_batches: how many searchers of this process have batches in flight next to each other (ShardedPipeline);
+        handed to the workspaces (kaamer_workspace_opts.concurrent_batches)."""
         assert transport in ("rccl", "torch", "host")
         self.index, self.rank, self.world, self.group = index, rank, world, group
         self.transport = transport
@@ -126,7 +128,7 @@ class ShardedSearcher:
         fp = 1 if first_pos else 2
         self.ws_first_pos = bool(first_pos)
         self.ws = api.Workspace(index, max_seq_bytes, max_seqs, seq_type=seq_type, first_pos=fp, max_hits=max_hits,
-                                g_tier_slots=g_tier_slots)
+                                g_tier_slots=g_tier_slots, concurrent_batches=concurrent_batches)
         self.layout = abi.ExchangeLayout()
         abi.check(abi.lib().kaamer_exchange_layout_init(world, rank, self.ws.query_capacity, max_entries_per_peer,
                                                         C.byref(self.layout)))
@@ -282,3 +284,56 @@ class ShardedSearcher:
             self.comm.close()
         self.ws.close()
         self.mws.close()
+
+
+class ShardedPipeline:
+    """Several sharded steps in flight: `depth` ShardedSearchers, each with its own workspaces, exchange buffers, stream
+    and (transport "rccl") communicator, take the batches in turn -- the all-to-all of batch i travels while batch i + 1 is
+    searched and batch i - 1 is merged.  Every rank enqueues the searchers in the same order, so the collectives of one
+    communicator (or of torch's process group) meet in the same order everywhere.  The block layout of a searcher's next
+    batch comes from ITS OWN earlier batches (kaamer_exchange_stats): the same figures on every rank."""
+
+    def __init__(self, depth, *args, **kw):
+        assert depth >= 1
+        kw = dict(kw, concurrent_batches=depth if depth > 1 else 0)
+        self.searchers = [ShardedSearcher(*args, **kw) for _ in range(depth)]
+        self.streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(depth - 1)]
+        self.n = 0
+        self.last_k = 0                       # the searcher that took the last batch
+        self.dirty = [False] * depth          # searchers with batches enqueued since their last finish
+
+    def __len__(self):
+        return len(self.searchers)
+
+    def step(self, d_seqs_ptr, d_off_ptr, n_seqs, seq_bytes, **kw):
+        """enqueue one batch on the next searcher -> (searcher index, DeviceResult)"""
+        k = self.n % len(self.searchers)
+        self.n += 1
+        self.last_k, self.dirty[k] = k, True
+        return k, self.searchers[k].step(d_seqs_ptr, d_off_ptr, n_seqs, seq_bytes, self.streams[k], **kw)
+
+    def finish(self):
+        """finish every searcher that has batches enqueued (all are finished before the first error is raised)
+        -> [(search counters, merge counters) or None], by searcher"""
+        out, err = [], None
+        for k, (s_, st) in enumerate(zip(self.searchers, self.streams)):
+            if not self.dirty[k]:
+                out.append(None)
+                continue
+            self.dirty[k] = False
+            try:
+                out.append(s_.finish(st))
+            except abi.KaamerError as e:
+                out.append(None)
+                err = err or e
+        if err is not None:
+            raise err
+        return out
+
+    def set_adaptive(self, on):
+        for s_ in self.searchers:
+            s_.adaptive = bool(on)
+
+    def close(self):
+        for s_ in self.searchers:
+            s_.close()

@@ -675,3 +675,64 @@ def test_sharded_handle_concurrent_callers(klib, oracle, gpu_device):
         t.join()
     sx.close()
     assert not errors, errors[:3]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("reads", [False, True])
+def test_sharded_steps_in_flight(klib, oracle, gpu_device, reads):
+    """ShardedPipeline: two searchers (workspaces, exchange buffers, streams of their own) take the batches in turn, so a
+    batch's exchange overlaps the next batch's search.  Eight batches of two different inputs through a pipeline of depth
+    two, at world 1 with the exchange code running (pack -> blocks -> merge): the reported hits of every batch equal the
+    oracle's, whichever searcher took it, and the adaptive block layout settles on each searcher by itself."""
+    import torch
+    from kaamer_amd import abi, api, sharded, workload
+    from oracle import oracle as O
+    torch.cuda.set_device(gpu_device)
+    db = workload.make_db(600, seed=6)
+    ix = api.Index.from_image(api.Image.from_proteins(packed=db), gpu_device)
+    full = O.Index.from_proteins(None, packed=db)
+    inputs = []
+    for seed in (12, 13):
+        if reads:
+            q = workload.make_reads(db, 250, seed=seed)
+            queries = [o for r in workload.unpack(q) for o in O.get_orfs(r)]
+        else:
+            queries = workload.unpack(workload.make_protein_queries(db, 120 + seed, seed=seed)) + [b"AAAAAAA", b""]
+            q = api.pack_sequences(queries)
+        inputs.append((q, queries, torch.from_numpy(q[0]).cuda(), torch.from_numpy(q[1].view(np.int64)).cuda()))
+    seq_type = abi.READS if reads else abi.PROTEIN
+    max_bytes = max(len(i[0][0]) for i in inputs)
+    max_seqs = max(len(i[0][1]) - 1 for i in inputs)
+    pipe = sharded.ShardedPipeline(2, ix, 0, 1, max_bytes, max_seqs, seq_type=seq_type, max_entries_per_peer=1 << 17,
+                                   transport="torch", first_pos=True)
+    assert len(pipe) == 2 and not pipe.searchers[0].direct
+    expected = [[_oracle_report(O, full, qq, reads)[1] for qq in queries] for _, queries, _, _ in inputs]
+
+    def check(k, which):
+        s_ = pipe.searchers[k]
+        queries = inputs[which][1]
+        t = s_.last_topn
+        tc = sharded.dev_tensor(t.d_top_cnt, len(queries), torch.int32).cpu().numpy()
+        tp = sharded.dev_tensor(t.d_top_pid, len(queries) * 10, torch.int32).cpu().numpy().view(np.uint32).reshape(-1, 10)
+        tk = sharded.dev_tensor(t.d_top_kmatch, len(queries) * 10, torch.int32).cpu().numpy().reshape(-1, 10)
+        for j in range(len(queries)):
+            exp_rep = expected[which][j]
+            assert int(tc[j]) == len(exp_rep), (k, which, j)
+            assert list(zip(tp[j, :len(exp_rep)].tolist(), tk[j, :len(exp_rep)].tolist())) == exp_rep, (k, which, j)
+
+    order = [0, 1, 1, 0, 0, 1, 0, 0]          # which input batch i carries: both searchers see both inputs
+    for i in range(0, len(order), 2):
+        took = []
+        for w in order[i:i + 2]:
+            q, queries, d_buf, d_off = inputs[w]
+            k, _ = pipe.step(d_buf.data_ptr(), d_off.data_ptr(), len(q[1]) - 1, len(q[0]), topn={})
+            took.append((k, w))
+        assert [k for k, _ in took] == [0, 1]
+        out = pipe.finish()
+        assert all(o is not None for o in out)
+        for k, w in took:
+            check(k, w)
+    for s_ in pipe.searchers:                # from its third batch on a searcher's blocks carry payload, not capacity
+        assert int(s_.wire.e_cap) < int(s_.layout.e_cap)
+    assert pipe.finish() == [None, None]     # nothing enqueued: nothing to finish
+    pipe.close()

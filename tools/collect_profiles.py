@@ -52,7 +52,8 @@ def short(k):
 
 os.makedirs(DST, exist_ok=True)
 for f in ("bench_default_n1", "bench_under_rocprof", "bench_inflight1_under_rocprof", "bench_reads_n1", "bench_reads_under_rocprof", "bench_reads_inflight1_under_rocprof", "bench_zipf", "bench_zipf_inflight1", "bench_reads_inflight3",
-          "bench_zipf_mid", "bench_mix", "bench_sharded_w1", "bench_sharded_reads_w1", "bench_sharded_default_w1", "bench_post_hostapi", "bench_reads_post_hostapi"):
+          "bench_zipf_mid", "bench_mix", "bench_sharded_w1", "bench_sharded_reads_w1", "bench_sharded_default_w1", "bench_post_hostapi", "bench_reads_post_hostapi",
+          "bench_default_with_sharded_leg_w1"):
     if os.path.exists(os.path.join(SRC, f + ".json")):
         shutil.copy(os.path.join(SRC, f + ".json"), os.path.join(DST, "%s_%s.json" % (R, f)))
 for f in ("random_read_bench.txt", "bucket_read_bench.txt", "sq_protein.txt", "sq_reads.txt"):
