@@ -736,3 +736,65 @@ def test_sharded_steps_in_flight(klib, oracle, gpu_device, reads):
         assert int(s_.wire.e_cap) < int(s_.layout.e_cap)
     assert pipe.finish() == [None, None]     # nothing enqueued: nothing to finish
     pipe.close()
+
+
+def _gpu_pipeline_worker(rank, world, port, ret):
+    """GPU: ranks that share GPU 0, each driving a ShardedPipeline of depth 2 (host transport over gloo): six batches of two
+    inputs; the reported hits of every batch equal those of a plain ShardedSearcher of the same rank on the same input."""
+    for p_ in (ROOT, os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p_)
+    import torch
+    import torch.distributed as dist
+    from kaamer_amd import abi, api, sharded, workload
+    _init_gloo(rank, world, port)
+    try:
+        torch.cuda.set_device(0)
+        db = workload.make_db(600, seed=6)
+        ix = api.Index.from_image(api.Image.from_proteins(packed=db, shard=rank, n_shards=world), 0)
+        inputs = []
+        for seed in (21, 22):
+            q = workload.make_protein_queries(db, 140 + seed, seed=seed)
+            inputs.append((q, torch.from_numpy(q[0]).cuda(), torch.from_numpy(q[1].view(np.int64)).cuda()))
+        max_bytes = max(len(i[0][0]) for i in inputs)
+        max_seqs = max(len(i[0][1]) - 1 for i in inputs)
+        kw = dict(seq_type=abi.PROTEIN, max_entries_per_peer=1 << 16, transport="host", first_pos=True)
+
+        def reported(s_, n_q):
+            owned = len(range(rank, n_q, world))
+            t = s_.last_topn
+            tc = sharded.dev_tensor(t.d_top_cnt, owned, torch.int32).cpu().numpy().copy()
+            tp = sharded.dev_tensor(t.d_top_pid, owned * 10, torch.int32).cpu().numpy().reshape(-1, 10).copy()
+            tk = sharded.dev_tensor(t.d_top_kmatch, owned * 10, torch.int32).cpu().numpy().reshape(-1, 10).copy()
+            return [(int(tc[j]), tp[j, :tc[j]].tolist(), tk[j, :tc[j]].tolist()) for j in range(owned)]
+        ref = sharded.ShardedSearcher(ix, rank, world, max_bytes, max_seqs, **kw)
+        want = []
+        for q, d_buf, d_off in inputs:
+            ref.run(d_buf.data_ptr(), d_off.data_ptr(), len(q[1]) - 1, len(q[0]), torch.cuda.current_stream(), topn={})
+            want.append(reported(ref, len(q[1]) - 1))
+        ref.close()
+        pipe = sharded.ShardedPipeline(2, ix, rank, world, max_bytes, max_seqs, **kw)
+        n = 0
+        for pair in ((0, 1), (1, 0), (0, 0)):
+            took = []
+            for w in pair:
+                q, d_buf, d_off = inputs[w]
+                k, _ = pipe.step(d_buf.data_ptr(), d_off.data_ptr(), len(q[1]) - 1, len(q[0]), topn={})
+                took.append((k, w))
+            pipe.finish()
+            for k, w in took:
+                got = reported(pipe.searchers[k], len(inputs[w][0][1]) - 1)
+                assert got == want[w], (rank, k, w)
+                n += sum(c for c, _, _ in got)
+        pipe.close()
+        ret[rank] = n
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_pipelined_sharded_steps_across_ranks(klib, oracle, gpu_device):
+    """two ranks (processes on GPU 0), each with two sharded steps in flight: the collectives of the two searchers meet in
+    the same order on both ranks (no hang), and every batch's reported hits are those of the one-step-at-a-time searcher"""
+    ret = _spawn(_gpu_pipeline_worker, 2)
+    assert len(ret) == 2 and all(v > 100 for v in ret.values()), ret
