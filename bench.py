@@ -635,9 +635,9 @@ def main():
                     dict({"G_random_requests_per_s": c["n_probe"] / probe_s / 1e9 if probe_s > 0 else 0.0,
                           "random_request_ceiling_G_per_s": 52.0},  # tools/random_read_bench.hip: 16..128-byte records alike
                          **alone("probe_ms", probe_bytes))),
-               kern(("count_async_kernel" if (args.inflight > 1 and not nucl and not sharded_mode) else
+               kern(("count_async_kernel" if (os.environ.get("KAAMER_COUNT_ASYNC", "0") not in ("", "0") and not nucl) else
                      "count_pack_kernel" if nucl else "count_group_kernel") + " (+ G tier, finalize)" +
-                    ("; alone_on_the_device: count_group_kernel, three workgroups per CU" if (args.inflight > 1 and not nucl and not sharded_mode) else ""),
+                    ("; one workgroup per CU in the timed region, three in alone_on_the_device" if (args.inflight > 1 and not nucl and not sharded_mode) else ""),
                     count_s, count_bytes, alone("count_ms", count_bytes))]
     kernels.sort(key=lambda k: -k["ms"])
     roofline = {

@@ -1847,16 +1847,13 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     // the reference fills PositionHits only for nucleotide/reads input or with -pos (search.go:416)
     ws->firstpos = opts->first_pos == 1 || (opts->first_pos == 0 && (opts->seq_type == KAAMER_NUCLEOTIDE || opts->seq_type == KAAMER_READS));
     int grp_per_cu = 0, p_per_cu = 0;
-    // Which counting kernel takes protein batches.  With batches of other workspaces next to this one (ONE counting
-    // workgroup per CU, below) the barrier-free kernel: its eight waves are all a CU has of this batch, and every wave that
-    // waits at a barrier is a hole in the CU's memory pipeline (same box, A/B/A/B: 0.1290-0.1308 against 0.1343-0.1344 ms per
-    // batch).  Alone on the device, three workgroups per CU, the round-3 kernel: the other workgroups fill one's barrier
-    // waits and the job counters only cost (95 against 115 us).  KAAMER_COUNT_ASYNC=0/1 forces either (the parity tests
-    // run both).
-    // (not on a database with postings lists longer than any counting table -- a skewed one: a window behind such a list keeps
-    // its group alive for long, two live groups per workgroup are not enough then and the static deal of the groups hurts:
-    // --db zipf 1.46 against 1.37 ms per batch, profiles/r04_experiments.md)
-    ws->count_async = opts->concurrent_batches > 1 && ix->hdr.max_list <= GRP_MAX_TABLE;
+    // Which counting kernel takes protein batches: count_group_kernel over units of two group windows (count_group.hip.inc).
+    // The barrier-free count_async_kernel (count_async.hip.inc; KAAMER_COUNT_ASYNC=1) beat the single-window group kernel
+    // when batches overlap (ONE counting workgroup per CU, below: 0.1290-0.1308 against 0.1343-0.1344 ms per batch, same box)
+    // and lost alone on the device (115 against 95 us); units then took the group kernel to 0.1268-0.1273 ms with three
+    // batches in flight (the barrier-free kernel in the same call: 0.1294-0.1320) and to 89 us alone
+    // (profiles/r04_experiments.md).  Both kernels stay under the parity tests (test_both_counting_kernels).
+    ws->count_async = false;
     if (const char *e = getenv("KAAMER_COUNT_ASYNC")) ws->count_async = atoi(e) != 0;
     hipError_t oe = ws->count_async
         ? (ws->firstpos ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&grp_per_cu, count_async_kernel<true>, 64 * GRP_WAVES, 0)
@@ -1916,7 +1913,10 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     ws->use_group = !ws->nucleotide;
     if (getenv("KAAMER_COUNT_GROUP")) ws->use_group = true;
     if (getenv("KAAMER_COUNT_PACK")) ws->use_group = false;
-    if (ws->use_group) ws->pack_shift = GRP_SHIFT;
+    // protein batches: count_group_kernel takes UNITS of two group windows (count_group.hip.inc); the barrier-free kernel
+    // keeps single windows (two of them alive in its arena)
+    if (ws->use_group) ws->pack_shift = ws->count_async ? GRP_SHIFT : GRP_SHIFT + 1u;
+    if (const char *e = getenv("KAAMER_GROUP_SHIFT")) { const int v = atoi(e); if (ws->use_group && !ws->count_async && (v == (int)GRP_SHIFT || v == (int)GRP_SHIFT + 1)) ws->pack_shift = (uint32_t)v; }
     // a table has at most max(64, 3 x SizeInKmer) slots
     {
         // (a merge counts partial entries instead of positions: as many as max_hits)
@@ -2034,7 +2034,7 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
 // table layout + query groups (count_group.hip.inc): one single-pass kernel
 static void launch_layout(kaamer_workspace *ws, uint32_t nq_bound, uint32_t *status, hipStream_t s, uint32_t bshift, bool schedule = true)
 {
-    const uint32_t cshift = bshift >= GRP_SHIFT ? 9u : 7u;  // 16 schedule classes over the slots a group / pack can hold
+    const uint32_t cshift = bshift > GRP_SHIFT ? 10u : bshift >= GRP_SHIFT ? 9u : 7u;  // 16 schedule classes over the slots a group / pack can hold
     ws->lay_epoch = (ws->lay_epoch + 1u) & 0xFFFFFFu;
     if (ws->lay_epoch == 0) ws->lay_epoch = 1;
     const uint32_t tiles = (uint32_t)(((uint64_t)nq_bound + 1 + LAY_TILE - 1) / LAY_TILE);
@@ -2156,7 +2156,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         pl.epoch = ws->lay_epoch;
         pl.status = status; pl.sched = ws->d_sched; pl.d_n_sched = ws->d_n_sched;
         pl.tiles_done = ws->d_list_counts + SLOT_TILES_DONE;
-        pl.slots = ws->d_slots; pl.bshift = ws->pack_shift; pl.cshift = ws->pack_shift >= GRP_SHIFT ? 9u : 7u;
+        pl.slots = ws->d_slots; pl.bshift = ws->pack_shift; pl.cshift = ws->pack_shift > GRP_SHIFT ? 10u : ws->pack_shift >= GRP_SHIFT ? 9u : 7u;
         // (KAAMER_SCHED_IDENTITY=1: no longest-first schedule, groups in index order -- an A/B knob)
         pl.no_sched = (ws->use_group && !ws->sched_identity) ? 0u : 1u;
         pl.d_total = ws->d_lay_total;
@@ -2358,6 +2358,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         uint64_t grp_blocks = ((uint64_t)GRP_MIN_TABLE * nq_bound + 3 * pos_bound) / GRP_BUDGET + 1;
         if (grp_blocks > (uint64_t)ws->grp_grid) grp_blocks = ws->grp_grid;
         CountParams pp2 = p;
+        pp2.pack_shift = GRP_SHIFT;   // (the layout just above)
         pp2.last_group_pass = 1u;
         pp2.pos_base = ws->d_pos_base;
         pp2.pos_bits = ws->d_pos_bits;
@@ -2431,6 +2432,7 @@ static int merge_device_impl(kaamer_workspace *ws, const uint64_t *d_ent_off, co
     p.d_n_groups = ws->d_n_groups;
     p.d_nq = ws->d_nq;
     p.last_group_pass = 1u;
+    p.pack_shift = GRP_SHIFT;
     p.group_queue = ws->d_list_counts + SLOT_GROUP_QUEUE;
     p.m_pid = d_pid; p.m_km = d_km; p.m_fp = d_fp; p.merge_fp = ws->firstpos ? 1u : 0u;
     p.list_cap = ws->q_cap;

@@ -345,9 +345,9 @@ def test_counting_tables_follow_the_previous_batch(klib, oracle, gpu_device):
 
 @pytest.mark.parametrize("first_pos", [1, -1])
 def test_both_counting_kernels(small, klib, oracle, gpu_device, first_pos, monkeypatch):
-    """A workspace that says other batches run next to its own (`concurrent_batches` > 1) counts protein batches with
-    the barrier-free kernel (count_async.hip.inc: window, stripe and build jobs from LDS counters, two groups alive per
-    workgroup), one that runs alone with count_group_kernel: same hit lists, first positions and counters from both,
+    """Protein batches are counted by count_group_kernel (units of two group windows per barrier cycle) or, with
+    KAAMER_COUNT_ASYNC=1, by the barrier-free kernel (count_async.hip.inc: window, stripe and build jobs from LDS counters,
+    two groups alive per workgroup): same hit lists, first positions and counters from both,
     equal to the oracle's -- on a ragged batch of many groups per workgroup, with empty and too-short queries, queries
     that leave their table for the G tier, and tables as large as the arena allows."""
     from kaamer_amd import api, workload
@@ -361,6 +361,8 @@ def test_both_counting_kernels(small, klib, oracle, gpu_device, first_pos, monke
     exp = _oracle_hits(oix, oracle, seqs)
     ref_c = None
     for cb in (0, 3):
+        # (cb = 3: the barrier-free kernel, which the library uses only when told to)
+        monkeypatch.setenv("KAAMER_COUNT_ASYNC", "1" if cb else "0")
         hits, first, c = _device_search(ix, seqs, first_pos=first_pos, concurrent_batches=cb)
         for i, (h, f) in enumerate(exp):
             assert hits[i] == h, (cb, i)
