@@ -1499,7 +1499,8 @@ struct kaamer_workspace {
     uint32_t *d_c_pid, *d_c_km, *d_c_fp;
     int g_grid, p_grid, n_cu, pack_grid, pack_grid_long;
     bool use_group;
-    bool count_async;                   // protein batches are counted by count_async_kernel (default) instead of count_group_kernel<., 0>
+    bool count_async;                   // protein batches are counted by count_async_kernel instead of count_group_kernel<., 0> (KAAMER_COUNT_ASYNC=1)
+    int unit_windows;                   // group windows per unit of count_group_kernel<., 0>: 2, or 4 with one workgroup per CU
     uint32_t pack_shift;                // log2 of the pack window (slots) of a search: 8 for protein, 10 for ORF batches
     // device buffers
     kaamer_query_meta *d_q;
@@ -1604,8 +1605,13 @@ template <class T> static int dev_alloc(T **p, size_t n)
     return KAAMER_OK;
 }
 
-static void launch_group(const CountParams &p, int grid, bool firstpos, hipStream_t s, bool async)
+static void launch_group(const CountParams &p, int grid, bool firstpos, hipStream_t s, bool async, int unit_windows)
 {
+    if (!async && unit_windows == 4) {   // units of four windows: 98 KB of LDS, one workgroup per CU (overlapping batches)
+        if (firstpos) hipLaunchKernelGGL((count_group_kernel<true, 0, 4>), dim3(grid), dim3(64 * GRP_WAVES), 0, s, p);
+        else hipLaunchKernelGGL((count_group_kernel<false, 0, 4>), dim3(grid), dim3(64 * GRP_WAVES), 0, s, p);
+        return;
+    }
     if (async) {   // the barrier-free form (count_async.hip.inc); KAAMER_COUNT_ASYNC=0: the round-3 kernel
         if (firstpos) hipLaunchKernelGGL((count_async_kernel<true>), dim3(grid), dim3(64 * GRP_WAVES), 0, s, p);
         else hipLaunchKernelGGL((count_async_kernel<false>), dim3(grid), dim3(64 * GRP_WAVES), 0, s, p);
@@ -1915,8 +1921,13 @@ int kaamer_workspace_create(kaamer_index *ix, const kaamer_workspace_opts *opts,
     if (getenv("KAAMER_COUNT_PACK")) ws->use_group = false;
     // protein batches: count_group_kernel takes UNITS of two group windows (count_group.hip.inc); the barrier-free kernel
     // keeps single windows (two of them alive in its arena)
-    if (ws->use_group) ws->pack_shift = ws->count_async ? GRP_SHIFT : GRP_SHIFT + 1u;
-    if (const char *e = getenv("KAAMER_GROUP_SHIFT")) { const int v = atoi(e); if (ws->use_group && !ws->count_async && (v == (int)GRP_SHIFT || v == (int)GRP_SHIFT + 1)) ws->pack_shift = (uint32_t)v; }
+    // (units of four windows -- an arena of 98 KB, one workgroup per CU: KAAMER_UNIT_WINDOWS=4 -- were measured for the
+    // overlapping launch, where there is one counting workgroup per CU anyway: 0.157-0.159 against 0.1255-0.1287 ms per batch;
+    // the probe kernels of the neighbouring batches miss the LDS and the registers.  Two it is.)
+    ws->unit_windows = 2;
+    if (const char *e = getenv("KAAMER_UNIT_WINDOWS")) { const int v = atoi(e); if (v == 2 || (v == 4 && grp_per_cu == 1)) ws->unit_windows = v; }
+    if (ws->use_group) ws->pack_shift = ws->count_async ? GRP_SHIFT : ws->unit_windows == 4 ? GRP_SHIFT + 2u : GRP_SHIFT + 1u;
+    if (const char *e = getenv("KAAMER_GROUP_SHIFT")) { const int v = atoi(e); if (ws->use_group && !ws->count_async && ws->unit_windows == 2 && (v == (int)GRP_SHIFT || v == (int)GRP_SHIFT + 1)) ws->pack_shift = (uint32_t)v; }
     // a table has at most max(64, 3 x SizeInKmer) slots
     {
         // (a merge counts partial entries instead of positions: as many as max_hits)
@@ -2303,7 +2314,7 @@ int kaamer_search_device(kaamer_index *ix, kaamer_workspace *ws, const uint8_t *
         if (ws->use_group) {
             uint64_t gg = ((uint64_t)GRP_MIN_TABLE * nq_bound + 3 * pos_bound) / GRP_BUDGET + 1;
             if (gg > (uint64_t)ws->grp_grid) gg = ws->grp_grid;
-            launch_group(pc, (int)gg, ws->firstpos, s, ws->count_async);
+            launch_group(pc, (int)gg, ws->firstpos, s, ws->count_async, ws->unit_windows);
         } else if (ws->nucleotide) {
             // reads of ~150 nt: ORFs of <= 50 residues, tables of 64-128 slots -> the small arena (20 waves per CU);
             // longer sequences (mixed read lengths, contigs): the arena that holds tables of up to 576 slots, or 66 000

@@ -345,7 +345,8 @@ def test_counting_tables_follow_the_previous_batch(klib, oracle, gpu_device):
 
 @pytest.mark.parametrize("first_pos", [1, -1])
 def test_both_counting_kernels(small, klib, oracle, gpu_device, first_pos, monkeypatch):
-    """Protein batches are counted by count_group_kernel (units of two group windows per barrier cycle) or, with
+    """Protein batches are counted by count_group_kernel (units of two group windows per barrier cycle; four with a larger
+    arena behind an experiment knob) or, with
     KAAMER_COUNT_ASYNC=1, by the barrier-free kernel (count_async.hip.inc: window, stripe and build jobs from LDS counters,
     two groups alive per workgroup): same hit lists, first positions and counters from both,
     equal to the oracle's -- on a ragged batch of many groups per workgroup, with empty and too-short queries, queries
@@ -360,9 +361,11 @@ def test_both_counting_kernels(small, klib, oracle, gpu_device, first_pos, monke
     seqs += workload.unpack(workload.make_protein_queries(db, 500, seed=6))
     exp = _oracle_hits(oix, oracle, seqs)
     ref_c = None
-    for cb in (0, 3):
-        # (cb = 3: the barrier-free kernel, which the library uses only when told to)
-        monkeypatch.setenv("KAAMER_COUNT_ASYNC", "1" if cb else "0")
+    # alone: three workgroups per CU; next to other batches: one, with units of two or (KAAMER_UNIT_WINDOWS=4, an experiment
+    # knob) four windows; the barrier-free kernel only when told to
+    for cb, asyn, uw in ((0, "0", "2"), (3, "0", "2"), (3, "0", "4"), (3, "1", "2")):
+        monkeypatch.setenv("KAAMER_COUNT_ASYNC", asyn)
+        monkeypatch.setenv("KAAMER_UNIT_WINDOWS", uw)
         hits, first, c = _device_search(ix, seqs, first_pos=first_pos, concurrent_batches=cb)
         for i, (h, f) in enumerate(exp):
             assert hits[i] == h, (cb, i)
@@ -383,9 +386,9 @@ def test_both_counting_kernels(small, klib, oracle, gpu_device, first_pos, monke
     fq = [core, bytes(alpha[rng.integers(0, 20, 300)]) + core + bytes(alpha[rng.integers(0, 20, 400)]), fam[7], core[:20]] * 6
     fq += [bytes(alpha[rng.integers(0, 20, int(n))]) for n in rng.integers(20, 900, 200)]
     fexp = _oracle_hits(foix, oracle, fq)
-    for cb in (0, 3):
-        # (on a table with lists this long the library keeps count_group_kernel by itself: the knob forces the other one)
-        monkeypatch.setenv("KAAMER_COUNT_ASYNC", "1" if cb else "0")
+    for cb, asyn, uw in ((0, "0", "2"), (3, "0", "4"), (3, "1", "2")):
+        monkeypatch.setenv("KAAMER_COUNT_ASYNC", asyn)
+        monkeypatch.setenv("KAAMER_UNIT_WINDOWS", uw)
         hits, first, c = _device_search(fix, fq, first_pos=first_pos, concurrent_batches=cb)
         for i, (h, f) in enumerate(fexp):
             assert hits[i] == h, (cb, i)
