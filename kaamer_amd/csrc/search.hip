@@ -2432,7 +2432,8 @@ static int merge_device_impl(kaamer_workspace *ws, const uint64_t *d_ent_off, co
     const int pb = 256;
     hipLaunchKernelGGL(prep_merge_kernel, dim3((n_queries + pb - 1) / pb > 0 ? (n_queries + pb - 1) / pb : 1), dim3(pb), 0, s, d_ent_off,
                        n_queries, d_n_queries, ws->d_qinfo, ws->d_slots, ws->d_nq, ws->d_hit_off, ws->d_q_cnt);
-    launch_layout(ws, nq_bound, status, s, GRP_SHIFT);
+    // (the merge runs on count_group_kernel<., 2>: units of two group windows, as the search of protein batches)
+    launch_layout(ws, nq_bound, status, s, GRP_SHIFT + 1u);
     CountParams p;
     memset(&p, 0, sizeof p);
     p.qinfo = ws->d_qinfo;
@@ -2443,7 +2444,7 @@ static int merge_device_impl(kaamer_workspace *ws, const uint64_t *d_ent_off, co
     p.d_n_groups = ws->d_n_groups;
     p.d_nq = ws->d_nq;
     p.last_group_pass = 1u;
-    p.pack_shift = GRP_SHIFT;
+    p.pack_shift = GRP_SHIFT + 1u;
     p.group_queue = ws->d_list_counts + SLOT_GROUP_QUEUE;
     p.m_pid = d_pid; p.m_km = d_km; p.m_fp = d_fp; p.merge_fp = ws->firstpos ? 1u : 0u;
     p.list_cap = ws->q_cap;
