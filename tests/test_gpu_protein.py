@@ -395,3 +395,33 @@ def test_both_counting_kernels(small, klib, oracle, gpu_device, first_pos, monke
             if first_pos == 1:
                 assert first[i] == f, (cb, i)
         assert c["n_overflow"] >= 12
+
+
+@pytest.mark.parametrize("first_pos", [1, -1])
+def test_units_that_do_not_fit_the_arena(small, oracle, first_pos):
+    """count_group_kernel counts a UNIT of two group windows per barrier cycle when the unit's tables fit its arena (sized
+    for one window's worst case) and in two cycles when they do not.  Runs of small queries followed by a query whose
+    table has the largest size (4 096 slots), repeated at shifting offsets of the layout, make units of up to 8 000 slots:
+    both forms, the second part's own descriptor loads, and hit lists that start where the layout says."""
+    from kaamer_amd import workload
+    db, img, ix, oix = small
+    rng = np.random.default_rng(17)
+    recs = workload.unpack(db)
+    big = [b"".join(recs[int(i)] for i in rng.integers(0, len(recs), 9))[:3100] for _ in range(6)]   # 3 094 k-mers: a 4 096-slot table
+    seqs = []
+    for rep in range(36):
+        n_small = 6 + rep % 9
+        for _ in range(n_small):
+            r = recs[int(rng.integers(0, len(recs)))]
+            seqs.append(r[: int(rng.integers(60, 320))])
+        seqs.append(big[rep % len(big)])
+        if rep % 4 == 0:
+            seqs.append(big[(rep + 1) % len(big)])        # two largest tables in a row
+    exp = _oracle_hits(oix, oracle, seqs)
+    for cb in (0, 3):
+        hits, first, c = _device_search(ix, seqs, first_pos=first_pos, concurrent_batches=cb)
+        for i, (h, f) in enumerate(exp):
+            assert hits[i] == h, (cb, i)
+            if first_pos == 1:
+                assert first[i] == f, (cb, i)
+        assert c["n_hits"] == sum(len(h) for h, _ in exp) and c["n_overflow"] <= 4
